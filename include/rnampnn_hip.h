@@ -1,0 +1,157 @@
+/*
+ * rnampnn_hip.h - C ABI of the MI355X-native RNA-MPNN forward path (librnampnn_hip.so).
+ *
+ * The reference (givemeone1astkiss/RNA-MPNN) has no FFI: its boundary for this path is the
+ * Python module surface of `rnampnn.model`.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference root).  The host-side mirror in
+ * `rna-mpnn_amd/rnampnn/model/` binds these symbols with ctypes and re-exposes the
+ * reference's class/method names; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers (HBM) unless
+ *     a parameter says "host"; tensors are dense row-major in the reference's layouts:
+ *       coords (B,T,7,3) f32, mask (B,T) f32 0/1 prefix masks as produced by the reference
+ *       collate (rnampnn/utils/data.py:110-142), logits (B,T,4) f32, edge_index (B,T,k) i64.
+ *   - inputs are const, outputs/workspace are caller-owned; the library keeps no reference
+ *     to them after return.  Weights are copied into library-owned HBM at set time.
+ *   - every launch goes to the caller's stream (`stream` = hipStream_t passed as void*), is
+ *     asynchronous and never synchronises the device (hipGraph-capturable).
+ *   - return value: 0 on success, an RNAMPNN_ERR_* code otherwise;
+ *     rnampnn_last_error() gives the message of the calling thread's last failure.
+ *   - one handle may be used by one host thread at a time (the reference: one Python
+ *     thread per process, one process per GPU).
+ */
+#ifndef RNAMPNN_HIP_H
+#define RNAMPNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNAMPNN_OK               0
+#define RNAMPNN_ERR_BAD_ARG      1  /* null pointer, negative size ...            -> ValueError        */
+#define RNAMPNN_ERR_UNSUPPORTED  2  /* hyper-parameter outside kernel support     -> NotImplementedError */
+#define RNAMPNN_ERR_T_GT_P       3  /* max_len > padding_len (functional.py:155)  -> RuntimeError      */
+#define RNAMPNN_ERR_K_TOO_LARGE  4  /* num_res_neighbours > RNAMPNN_KMAX          -> NotImplementedError */
+#define RNAMPNN_ERR_WORKSPACE    5  /* workspace smaller than rnampnn_workspace_bytes -> RuntimeError  */
+#define RNAMPNN_ERR_WEIGHTS      6  /* unknown key / wrong shape / weight not set -> KeyError          */
+#define RNAMPNN_ERR_HIP          7  /* HIP runtime error (message carries hipGetErrorString)           */
+
+#define RNAMPNN_KMAX 32             /* neighbours per residue supported by the edge kernels */
+
+#define RNAMPNN_PREC_F32  0         /* exact-f32 kernels (parity grade: |dlogit| <= 1e-4)   */
+#define RNAMPNN_PREC_BF16 1         /* bf16 MFMA operands, f32 accumulate, bf16 edge tensor */
+
+typedef struct rnampnn_ctx* rnampnn_handle;
+
+/* Hyper-parameters of RNAMPNN.__init__ that shape the network (rnampnn/model/rnampnn.py:19-47).
+ * Atom counts are fixed at the reference defaults 7/6/6 (28 node and 90 edge raw features). */
+typedef struct RnaMpnnConfig {
+    int32_t num_res_neighbours;
+    int32_t res_embedding_dim;            /* must be 128 */
+    int32_t num_embedding_attn_layers;
+    int32_t num_embedding_heads;
+    int32_t embedding_ffn_dim;
+    int32_t num_embedding_ffn_layers;
+    int32_t res_edge_embedding_dim;       /* must be 128 */
+    int32_t depth_res_edge_feature;       /* 1..2 */
+    int32_t num_res_mpnn_layers;
+    int32_t depth_res_mpnn;               /* 1..2 */
+    int32_t num_mpnn_edge_layers;         /* 1..2 */
+    int32_t padding_len;
+    int32_t num_post_fusion_attn_layers;
+    int32_t num_post_fusion_heads;
+    int32_t post_fusion_ffn_dim;
+    int32_t num_post_fusion_ffn_layers;
+    int32_t num_raw_ffn_dim;
+    int32_t num_raw_ffn_layers;
+    int32_t raw_embedding_dim;            /* must be 128 */
+    int32_t readout_hidden_dim;
+    int32_t num_readout_layers;
+    int32_t precision;                    /* RNAMPNN_PREC_* */
+} RnaMpnnConfig;
+
+/* Inputs, outputs and optional intermediate taps of one forward pass.  Null taps are skipped.
+ * All taps are written in the reference's padded layouts with the reference's padding values. */
+typedef struct RnaMpnnForwardIO {
+    const float* coords;      /* (B,T,7,3) */
+    const float* mask;        /* (B,T)     */
+    int32_t B, T;
+    int32_t T_norm;           /* node-axis length seen by GraphNormalization (functional.py:33-38);
+                                 0 = T.  A data-parallel shard passes the GLOBAL batch max_len here. */
+    int32_t stop_after;       /* 0 = whole forward; 1 = stop after ResFeature.forward (feature.py:573-592) */
+    float*   logits;          /* (B,T,4)    RNAMPNN.forward          rnampnn.py:161-185 (required if stop_after==0) */
+    float*   embedding;       /* (B,T,256)  RNAMPNN.embedding        rnampnn.py:269-278 */
+    int64_t* edge_index;      /* (B,T,k)    ResFeature._get_res_graph feature.py:205-256 */
+    float*   raw;             /* (B,T,28)   ResFeature._res_embedding feature.py:531-535 */
+    float*   h0;              /* (B,T,128)  node embedding after ResFeature.graph_norm feature.py:591 */
+    float*   e0;              /* (B,T,k,128) ResFeature._res_edge_embedding feature.py:540-571 */
+    int32_t  tap_layer;       /* 1-based ResMPNN layer whose outputs go to h_layer/e_layer; 0 = none */
+    float*   h_layer;         /* (B,T,128)   ResMPNN.forward h  mpnn.py:283-294 */
+    float*   e_layer;         /* (B,T,k,128) ResMPNN.forward e (valid edges; invalid slots are 0) */
+    float*   h_post;          /* (B,T,128)  RNABert post_fusion      functional.py:161-172 */
+    float*   raw_emb;         /* (B,T,128)  RawFFN                    functional.py:200-202 */
+} RnaMpnnForwardIO;
+
+/* -- lifetime / weights ------------------------------------------------------------------ */
+/* RNAMPNN.__init__ (rnampnn.py:94-134): validates hyper-parameters, allocates weight storage. */
+int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out);
+int rnampnn_destroy(rnampnn_handle h);
+/* nn.Module.load_state_dict for one entry: `key` is the reference state_dict key (SURVEY.md
+ * row A1), `data` an f32 tensor with `numel` elements on the device (is_host=0) or host (1). */
+int rnampnn_set_weight(rnampnn_handle h, const char* key, const float* data, int64_t numel,
+                       int32_t is_host, void* stream);
+/* Number of state-dict entries the configuration expects; key/numel of entry i (host strings). */
+int rnampnn_num_weights(rnampnn_handle h);
+int rnampnn_weight_info(rnampnn_handle h, int32_t i, const char** key, int64_t* numel);
+/* Builds the kernel-side layouts (transposes, bf16 fragment images) from the weights set so far. */
+int rnampnn_finalize_weights(rnampnn_handle h, void* stream);
+
+/* -- forward ----------------------------------------------------------------------------- */
+size_t rnampnn_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
+/* RNAMPNN.forward / RNAMPNN.embedding / ResFeature.forward, by `io->stop_after` and taps. */
+int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* -- stage entry points (parity tests and the standalone reference classes) -------------- */
+/* ResMPNN.forward / ResMPNN.message (mpnn.py:154-194, 267-294) for layer `layer` (0-based) on
+ * caller-supplied h (B,T,128), e (B,T,k,128), edge_index (B,T,k) i64.  msg_out (B,T,k,128),
+ * h_out, e_out are optional (null = skip). */
+int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* h_in, const float* e_in,
+                       const int64_t* edge_index, const float* mask, int32_t B, int32_t T, int32_t T_norm,
+                       float* msg_out, float* h_out, float* e_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* GraphNormalization.forward (functional.py:18-48); T_tot = node-axis length entering the variance. */
+int rnampnn_graph_norm(const float* x, const float* mask, const float* scale, const float* shift,
+                       int32_t B, int32_t T, int32_t T_tot, int32_t D, float* y, void* stream);
+/* RNABert.forward (functional.py:161-172): which = 0 res_feature.res_embedding, 1 post_fusion. */
+int rnampnn_rnabert(rnampnn_handle h, int32_t which, const float* x, const float* mask, int32_t B, int32_t T,
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* RawFFN.forward (functional.py:200-202): raw (B,T,28) -> (B,T,128). */
+int rnampnn_raw_ffn(rnampnn_handle h, const float* raw, const float* mask, int32_t B, int32_t T, int32_t T_norm,
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* Readout.forward (functional.py:86-90): emb (B,T,256) -> logits (B,T,4). */
+int rnampnn_readout(rnampnn_handle h, const float* emb, const float* mask, int32_t B, int32_t T,
+                    float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* -- decode ------------------------------------------------------------------------------ */
+/* argmax decode + recovery (rnampnn.py:223-230, utils/train.py:18-21): per-RNA counts of correct
+ * and valid positions, pred (B,T) int8 (-1 on padding).  labels (B,T) int32 class ids. */
+int rnampnn_argmax_recovery(const float* logits, const float* mask, const int32_t* labels,
+                            int32_t B, int32_t T, int8_t* pred, int32_t* correct, int32_t* valid, void* stream);
+/* sample(): independent categorical draw per position from softmax(logits / temperature)
+ * (no reference counterpart).  out (n_samples,B,T) int8, -1 on padding.
+ * Counter-based RNG: draw = f(seed, sample, b, t) - reproducible and graph-replay safe. */
+int rnampnn_sample(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
+                   int32_t n_samples, uint64_t seed, int8_t* out, void* stream);
+
+const char* rnampnn_last_error(void);
+const char* rnampnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNAMPNN_HIP_H */

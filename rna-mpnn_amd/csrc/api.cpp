@@ -1,0 +1,699 @@
+// C-ABI layer of librnampnn_hip.so: handle, weight registry, workspace carving and the launch
+// sequence of one forward pass.  See include/rnampnn_hip.h for the contract of every symbol.
+#include "../../include/rnampnn_hip.h"
+#include "rnampnn_internal.h"
+#include "kernels_bf16.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) return fail(RNAMPNN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char* rnampnn_last_error(void) { return g_err; }
+extern "C" const char* rnampnn_version(void) { return "rnampnn-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------
+struct RawT {                 // one state_dict entry in the reference's layout
+    std::string key;
+    int64_t numel;
+    size_t off;               // float offset in the raw arena
+    bool set;
+};
+
+struct Lin {                  // nn.Linear
+    int in, out, in_pad;
+    int w, b;                 // RawT indices
+    size_t wt;                // derived: K-major f32 [in_pad][out]
+    size_t wb;                // derived: bf16 [out][in_pad] (fast path), or (size_t)-1
+    bool gelu;
+};
+struct Attn { Lin qkv, out; int gn_scale, gn_shift; };
+struct Bert { std::vector<Attn> attn; std::vector<Lin> ffn; int heads; };
+struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
+    int depth;
+    int w[2], b[2];           // RawT indices
+    size_t pq_t, pq_b;        // derived f32: [128][256] K-major (P | Q parts of Linear 0), bias [b1 | 0]
+    size_t wc_t, w2_t;        // derived f32: e-part of Linear 0 and Linear 1, K-major
+    size_t pq_wb;             // derived bf16 [256][128]  (fast path node GEMM)
+    size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
+    size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
+};
+struct MpnnLayer { int gn_scale, gn_shift; Mlp2 msg, edge; };
+
+struct rnampnn_ctx {
+    RnaMpnnConfig cfg;
+    std::vector<RawT> raw;
+    size_t raw_floats = 0;
+    float* raw_arena = nullptr;
+    size_t der_bytes = 0;
+    char* der_arena = nullptr;
+    bool finalized = false;
+    // structure
+    Lin raw_project;
+    Bert emb, post;
+    int feat_gn_scale, feat_gn_shift;
+    std::vector<Lin> edge_embed;
+    size_t edge_embed_img = 0;    // bf16 fragment image for the fast path
+    std::vector<MpnnLayer> mpnn;
+    std::vector<Lin> raw_ffn;
+    int rawffn_gn_scale, rawffn_gn_shift;
+    std::vector<Lin> readout;
+    int fmax = 0;                 // widest node activation
+};
+
+static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {
+    RawT t{key, numel, c->raw_floats, false};
+    c->raw_floats += (size_t)((numel + 3) / 4 * 4);
+    c->raw.push_back(t);
+    return (int)c->raw.size() - 1;
+}
+static size_t add_der(rnampnn_ctx* c, size_t bytes) {
+    size_t off = c->der_bytes;
+    c->der_bytes += (bytes + 255) / 256 * 256;
+    return off;
+}
+static Lin make_lin(rnampnn_ctx* c, const std::string& prefix, int in, int out, bool gelu) {
+    Lin l;
+    l.in = in; l.out = out; l.in_pad = (in + 31) / 32 * 32; l.gelu = gelu;
+    l.w = add_raw(c, prefix + ".weight", (int64_t)in * out);
+    l.b = add_raw(c, prefix + ".bias", out);
+    l.wt = add_der(c, (size_t)l.in_pad * out * sizeof(float));
+    l.wb = add_der(c, (size_t)l.in_pad * out * sizeof(bf16_t));
+    if (out > c->fmax) c->fmax = out;
+    return l;
+}
+static void make_gn(rnampnn_ctx* c, const std::string& prefix, int& scale, int& shift) {
+    scale = add_raw(c, prefix + ".scale", RN_D);
+    shift = add_raw(c, prefix + ".shift", RN_D);
+}
+static Bert make_bert(rnampnn_ctx* c, const std::string& prefix, int n_attn, int heads, int ffn_dim, int n_ffn) {
+    Bert b;
+    b.heads = heads;
+    for (int j = 0; j < n_attn; ++j) {              // registration order = torch state_dict order
+        Attn a;
+        std::string p = prefix + ".bi_attention_layers." + std::to_string(j);
+        a.qkv.in = RN_D; a.qkv.out = 3 * RN_D; a.qkv.in_pad = RN_D; a.qkv.gelu = false;
+        a.qkv.w = add_raw(c, p + ".in_proj_weight", 3 * RN_D * RN_D);
+        a.qkv.b = add_raw(c, p + ".in_proj_bias", 3 * RN_D);
+        a.qkv.wt = add_der(c, (size_t)RN_D * 3 * RN_D * sizeof(float));
+        a.qkv.wb = add_der(c, (size_t)RN_D * 3 * RN_D * sizeof(bf16_t));
+        a.out = make_lin(c, p + ".out_proj", RN_D, RN_D, false);
+        b.attn.push_back(a);
+    }
+    if (3 * RN_D > c->fmax && n_attn > 0) c->fmax = 3 * RN_D;
+    for (int j = 0; j < n_attn; ++j)
+        make_gn(c, prefix + ".graph_norm_layers." + std::to_string(j), b.attn[j].gn_scale, b.attn[j].gn_shift);
+    int in = RN_D;
+    for (int i = 0; i < n_ffn; ++i) {
+        b.ffn.push_back(make_lin(c, prefix + ".ffn_layers." + std::to_string(3 * i), in, ffn_dim, true));
+        in = ffn_dim;
+    }
+    b.ffn.push_back(make_lin(c, prefix + ".ffn_layers." + std::to_string(3 * n_ffn), ffn_dim, RN_D, false));
+    return b;
+}
+static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
+    Mlp2 m;
+    m.depth = depth;
+    m.w[1] = m.b[1] = -1;
+    for (int i = 0; i < depth; ++i) {
+        std::string p = prefix + "." + std::to_string(3 * i);
+        m.w[i] = add_raw(c, p + ".weight", (int64_t)RN_D * (i == 0 ? 3 * RN_D : RN_D));
+        m.b[i] = add_raw(c, p + ".bias", RN_D);
+    }
+    m.pq_t = add_der(c, (size_t)RN_D * 256 * sizeof(float));
+    m.pq_b = add_der(c, 256 * sizeof(float));
+    m.wc_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
+    m.w2_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
+    m.pq_wb = add_der(c, (size_t)256 * RN_D * sizeof(bf16_t));
+    m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
+    m.b2p = add_der(c, RN_D * sizeof(float));
+    return m;
+}
+
+extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
+    if (!cfg || !out) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_create: null argument");
+    const RnaMpnnConfig& g = *cfg;
+    if (g.res_embedding_dim != RN_D || g.res_edge_embedding_dim != RN_D || g.raw_embedding_dim != RN_D)
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "embedding dims must be 128 (got %d/%d/%d)", g.res_embedding_dim,
+                    g.res_edge_embedding_dim, g.raw_embedding_dim);
+    if (g.num_res_neighbours < 1) return fail(RNAMPNN_ERR_BAD_ARG, "num_res_neighbours must be >= 1");
+    if (g.num_res_neighbours > RNAMPNN_KMAX)
+        return fail(RNAMPNN_ERR_K_TOO_LARGE, "num_res_neighbours %d > %d", g.num_res_neighbours, RNAMPNN_KMAX);
+    auto depth_ok = [](int d) { return d >= 1 && d <= 2; };
+    if (!depth_ok(g.depth_res_edge_feature) || !depth_ok(g.depth_res_mpnn) || !depth_ok(g.num_mpnn_edge_layers))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "edge / message MLP depth must be 1 or 2");
+    auto dim_ok = [](int d) { return d >= 32 && d <= 2048 && d % 32 == 0; };
+    if (!dim_ok(g.embedding_ffn_dim) || !dim_ok(g.post_fusion_ffn_dim) || !dim_ok(g.num_raw_ffn_dim) ||
+        !dim_ok(g.readout_hidden_dim))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "FFN widths must be multiples of 32 in [32, 2048]");
+    if (g.num_embedding_ffn_layers < 1 || g.num_post_fusion_ffn_layers < 1 || g.num_raw_ffn_layers < 1 ||
+        g.num_readout_layers < 1 || g.num_res_mpnn_layers < 1)
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "layer counts must be >= 1");
+    auto heads_ok = [](int n_attn, int h) { return n_attn == 0 || h == 2 || h == 4 || h == 8 || h == 16; };
+    if (g.num_embedding_attn_layers < 0 || g.num_post_fusion_attn_layers < 0 ||
+        !heads_ok(g.num_embedding_attn_layers, g.num_embedding_heads) ||
+        !heads_ok(g.num_post_fusion_attn_layers, g.num_post_fusion_heads))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "attention heads must be 2, 4, 8 or 16");
+    if (g.padding_len < 1) return fail(RNAMPNN_ERR_BAD_ARG, "padding_len must be positive");
+    if (g.precision != RNAMPNN_PREC_F32 && g.precision != RNAMPNN_PREC_BF16)
+        return fail(RNAMPNN_ERR_BAD_ARG, "unknown precision %d", g.precision);
+#ifndef RN_FAST_READY
+    if (g.precision == RNAMPNN_PREC_BF16)
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "this build carries the f32 kernels only");
+#endif
+    if (g.precision == RNAMPNN_PREC_BF16 &&
+        (g.depth_res_edge_feature != 2 || g.depth_res_mpnn != 2 || g.num_mpnn_edge_layers != 2))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "the bf16 kernels cover the default MLP depth 2 only; use precision f32");
+
+    rnampnn_ctx* c = new rnampnn_ctx();
+    c->cfg = g;
+    c->fmax = 3 * RN_D;
+    // registration order follows torch's state_dict order of RNAMPNN (rnampnn.py:94-134)
+    c->raw_project = make_lin(c, "res_feature.raw_project", RN_RAW, RN_D, false);
+    c->emb = make_bert(c, "res_feature.res_embedding", g.num_embedding_attn_layers, g.num_embedding_heads,
+                       g.embedding_ffn_dim, g.num_embedding_ffn_layers);
+    make_gn(c, "res_feature.graph_norm", c->feat_gn_scale, c->feat_gn_shift);
+    for (int i = 0; i < g.depth_res_edge_feature; ++i)
+        c->edge_embed.push_back(make_lin(c, "res_feature.res_edge_embedding_layers." + std::to_string(3 * i),
+                                         i == 0 ? RN_ERAW : RN_D, RN_D, true));
+    c->edge_embed_img = add_der(c, (size_t)(RN_ERAWP + RN_D) * RN_D * sizeof(bf16_t));
+    for (int l = 0; l < g.num_res_mpnn_layers; ++l) {
+        MpnnLayer m;
+        std::string p = "res_mpnn_layers." + std::to_string(l);
+        make_gn(c, p + ".graph_norm", m.gn_scale, m.gn_shift);
+        m.msg = make_mlp2(c, p + ".message_layers", g.depth_res_mpnn);
+        m.edge = make_mlp2(c, p + ".edge_layers", g.num_mpnn_edge_layers);
+        c->mpnn.push_back(m);
+    }
+    c->post = make_bert(c, "post_fusion", g.num_post_fusion_attn_layers, g.num_post_fusion_heads,
+                        g.post_fusion_ffn_dim, g.num_post_fusion_ffn_layers);
+    {
+        int in = RN_RAW;
+        for (int i = 0; i < g.num_raw_ffn_layers; ++i) {
+            c->raw_ffn.push_back(make_lin(c, "raw_embedding.raw_ffn." + std::to_string(3 * i), in, g.num_raw_ffn_dim, true));
+            in = g.num_raw_ffn_dim;
+        }
+        c->raw_ffn.push_back(make_lin(c, "raw_embedding.raw_ffn." + std::to_string(3 * g.num_raw_ffn_layers),
+                                      g.num_raw_ffn_dim, RN_D, false));
+        make_gn(c, "raw_embedding.graph_norm", c->rawffn_gn_scale, c->rawffn_gn_shift);
+    }
+    {
+        int in = 2 * RN_D;
+        for (int i = 0; i < g.num_readout_layers - 1; ++i) {
+            c->readout.push_back(make_lin(c, "readout.readout_layers." + std::to_string(3 * i), in, g.readout_hidden_dim, true));
+            in = g.readout_hidden_dim;
+        }
+        c->readout.push_back(make_lin(c, "readout.readout_layers." + std::to_string(3 * (g.num_readout_layers - 1)),
+                                      in, 4, false));
+    }
+    *out = c;
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_destroy(rnampnn_handle h) {
+    if (!h) return RNAMPNN_OK;
+    if (h->raw_arena) (void)hipFree(h->raw_arena);
+    if (h->der_arena) (void)hipFree(h->der_arena);
+    delete h;
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_num_weights(rnampnn_handle h) { return h ? (int)h->raw.size() : 0; }
+
+extern "C" int rnampnn_weight_info(rnampnn_handle h, int32_t i, const char** key, int64_t* numel) {
+    if (!h || i < 0 || i >= (int)h->raw.size()) return fail(RNAMPNN_ERR_BAD_ARG, "weight index out of range");
+    if (key) *key = h->raw[i].key.c_str();
+    if (numel) *numel = h->raw[i].numel;
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_set_weight(rnampnn_handle h, const char* key, const float* data, int64_t numel,
+                                  int32_t is_host, void* stream) {
+    if (!h || !key || !data) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_set_weight: null argument");
+    if (!h->raw_arena) {
+        HIP_TRY(hipMalloc((void**)&h->raw_arena, h->raw_floats * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&h->der_arena, h->der_bytes));
+    }
+    for (auto& t : h->raw) {
+        if (t.key == key) {
+            if (t.numel != numel)
+                return fail(RNAMPNN_ERR_WEIGHTS, "weight '%s': expected %lld elements, got %lld", key,
+                            (long long)t.numel, (long long)numel);
+            HIP_TRY(hipMemcpyAsync(h->raw_arena + t.off, data, (size_t)numel * sizeof(float),
+                                   is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            t.set = true;
+            h->finalized = false;
+            return RNAMPNN_OK;
+        }
+    }
+    return fail(RNAMPNN_ERR_WEIGHTS, "unknown state_dict key '%s'", key);
+}
+
+// ------------------------------------------------------------------------------------------
+static inline float* rawp(rnampnn_ctx* c, int idx) { return c->raw_arena + c->raw[idx].off; }
+template <typename T> static inline T* derp(rnampnn_ctx* c, size_t off) { return reinterpret_cast<T*>(c->der_arena + off); }
+
+static void finalize_lin(rnampnn_ctx* c, const Lin& l, hipStream_t s) {
+    launch_transpose(rawp(c, l.w), l.in, l.out, l.in, derp<float>(c, l.wt), l.out, s);
+    if (c->cfg.precision == RNAMPNN_PREC_BF16)
+        launch_convert_rows_bf16(rawp(c, l.w), l.in, l.out, l.in, l.in_pad, derp<bf16_t>(c, l.wb), s);
+}
+static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, hipStream_t s) {
+    const float* w0 = rawp(c, m.w[0]);                 // [128][384] = [out][h_i | h_j | e]
+    float* pq = derp<float>(c, m.pq_t);
+    launch_transpose(w0, 3 * RN_D, RN_D, RN_D, pq, 256, s);                    // P part
+    launch_transpose(w0 + RN_D, 3 * RN_D, RN_D, RN_D, pq + RN_D, 256, s);      // Q part
+    (void)hipMemcpyAsync(derp<float>(c, m.pq_b), rawp(c, m.b[0]), RN_D * sizeof(float), hipMemcpyDeviceToDevice, s);
+    launch_transpose(w0 + 2 * RN_D, 3 * RN_D, RN_D, RN_D, derp<float>(c, m.wc_t), RN_D, s);
+    if (m.depth > 1) launch_transpose(rawp(c, m.w[1]), RN_D, RN_D, RN_D, derp<float>(c, m.w2_t), RN_D, s);
+    if (c->cfg.precision == RNAMPNN_PREC_BF16) {
+        // node GEMM weights [P rows | Q rows] = W0[:, 0:128] and W0[:, 128:256], bf16 [256][128]
+        launch_convert_rows_bf16(w0, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb), s);
+        launch_convert_rows_bf16(w0 + RN_D, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb) + RN_D * RN_D, s);
+        launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]),
+                               derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
+    }
+}
+
+extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
+    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+    if (!h->raw_arena) return fail(RNAMPNN_ERR_WEIGHTS, "no weights have been set");
+    for (auto& t : h->raw)
+        if (!t.set) return fail(RNAMPNN_ERR_WEIGHTS, "weight '%s' has not been set", t.key.c_str());
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(h->der_arena, 0, h->der_bytes, s));
+    finalize_lin(h, h->raw_project, s);
+    for (Bert* b : {&h->emb, &h->post}) {
+        for (auto& a : b->attn) { finalize_lin(h, a.qkv, s); finalize_lin(h, a.out, s); }
+        for (auto& l : b->ffn) finalize_lin(h, l, s);
+    }
+    for (auto& l : h->edge_embed) finalize_lin(h, l, s);
+    for (auto& m : h->mpnn) { finalize_mlp2(h, m.msg, s); finalize_mlp2(h, m.edge, s); }
+    for (auto& l : h->raw_ffn) finalize_lin(h, l, s);
+    for (auto& l : h->readout) finalize_lin(h, l, s);
+    if (h->cfg.precision == RNAMPNN_PREC_BF16)
+        launch_build_embed_image(rawp(h, h->edge_embed[0].w), rawp(h, h->edge_embed[1].w),
+                                 derp<bf16_t>(h, h->edge_embed_img), s);
+    HIP_TRY(hipGetLastError());
+    h->finalized = true;
+    return RNAMPNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Ws {                       // workspace carve (all offsets 256-byte aligned)
+    int *len, *cu, *node_b, *nbr;
+    float *geom, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
+    void* e;                      // f32 or bf16 [Nmax*k][128]
+    float* big;                   // [Nmax*k][128] f32 scratch for the stage API / edge taps
+    size_t total;
+};
+
+static size_t carve(const rnampnn_ctx* c, int B, int T, char* base, Ws* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
+    size_t Nmax = (size_t)B * T, k = c->cfg.num_res_neighbours, F = c->fmax;
+    size_t esz = c->cfg.precision == RNAMPNN_PREC_BF16 ? sizeof(bf16_t) : sizeof(float);
+    Ws tmp;
+    Ws& r = w ? *w : tmp;
+    r.len = (int*)take(B * sizeof(int));
+    r.cu = (int*)take((B + 1) * sizeof(int));
+    r.node_b = (int*)take(Nmax * sizeof(int));
+    r.nbr = (int*)take(Nmax * k * sizeof(int));
+    r.geom = (float*)take((Nmax + B) * RN_GEOM * sizeof(float));
+    r.raw_p = (float*)take(Nmax * RN_RAWP * sizeof(float));
+    r.hA = (float*)take((Nmax + 1) * RN_D * sizeof(float));
+    r.hB = (float*)take((Nmax + 1) * RN_D * sizeof(float));
+    r.pq_e = (float*)take((Nmax + 1) * 256 * sizeof(float));
+    r.pq_m = (float*)take((Nmax + 1) * 256 * sizeof(float));
+    r.s0 = (float*)take(Nmax * F * sizeof(float));
+    r.s1 = (float*)take(Nmax * F * sizeof(float));
+    r.n0 = (float*)take(Nmax * RN_D * sizeof(float));
+    r.n1 = (float*)take(Nmax * RN_D * sizeof(float));
+    r.n2 = (float*)take(Nmax * RN_D * sizeof(float));
+    r.logits_p = (float*)take(Nmax * 4 * sizeof(float));
+    r.e = (void*)take(Nmax * k * RN_D * esz);
+    r.big = (float*)take(Nmax * k * RN_D * sizeof(float));
+    r.total = off;
+    return off;
+}
+
+extern "C" size_t rnampnn_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    return carve(h, B, T, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+struct Run {                      // one call's launch context
+    rnampnn_ctx* c;
+    PackInfo pk;
+    Ws w;
+    hipStream_t s;
+    bool fast;
+    const int* ntot() const { return pk.cu + pk.B; }
+};
+
+static void gemm(Run& r, const Lin& l, const float* X, int ldx, float* Y, int ldy, const float* res = nullptr,
+                 int ldres = 0, const float* X2 = nullptr, int ldx2 = 0, int K1 = -1) {
+    rnampnn_ctx* c = r.c;
+    int k1 = K1 < 0 ? l.in_pad : K1;
+    int k2 = K1 < 0 ? 0 : l.in_pad - K1;
+    if (r.fast && l.out >= 64)
+        launch_gemm_bf16(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<bf16_t>(c, l.wb), rawp(c, l.b), l.out,
+                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
+    else
+        launch_gemm_f32(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<float>(c, l.wt), rawp(c, l.b), l.out,
+                        l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
+}
+
+// RNABert.forward on packed rows: x [N][128] -> out [N][128] (x is clobbered when attention layers exist)
+static int run_bert(Run& r, const Bert& b, float* x, float* out) {
+    rnampnn_ctx* c = r.c;
+    for (auto& a : b.attn) {
+        gemm(r, a.qkv, x, RN_D, r.w.s0, 3 * RN_D);
+        if (launch_attention_f32(r.pk, r.w.s0, b.heads, r.w.n2, r.s)) return fail(RNAMPNN_ERR_UNSUPPORTED, "head dim unsupported");
+        gemm(r, a.out, r.w.n2, RN_D, r.w.s1, RN_D, x, RN_D);                          // x + out_proj(attn)
+        launch_graph_norm_packed(r.pk, r.w.s1, x, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s);
+    }
+    const float* cur = x;
+    int ld = RN_D;
+    float* bufs[2] = {r.w.s0, r.w.s1};
+    for (size_t i = 0; i < b.ffn.size(); ++i) {
+        const Lin& l = b.ffn[i];
+        bool last = i + 1 == b.ffn.size();
+        float* dst = last ? out : bufs[i & 1];
+        gemm(r, l, cur, ld, dst, l.out);
+        cur = dst; ld = l.out;
+    }
+    return RNAMPNN_OK;
+}
+
+static void run_ffn(Run& r, const std::vector<Lin>& ffn, const float* x, int ldx, float* out) {
+    const float* cur = x;
+    int ld = ldx;
+    float* bufs[2] = {r.w.s0, r.w.s1};
+    for (size_t i = 0; i < ffn.size(); ++i) {
+        bool last = i + 1 == ffn.size();
+        float* dst = last ? out : bufs[i & 1];
+        gemm(r, ffn[i], cur, ld, dst, ffn[i].out);
+        cur = dst; ld = ffn[i].out;
+    }
+}
+
+static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq) {
+    rnampnn_ctx* c = r.c;
+    if (r.fast)
+        launch_gemm_bf16(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<bf16_t>(c, m.pq_wb),
+                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
+    else
+        launch_gemm_f32(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<float>(c, m.pq_t),
+                        derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
+}
+
+static MpnnW32 w32(rnampnn_ctx* c, const Mlp2& m) {
+    MpnnW32 w;
+    w.wc_t = derp<float>(c, m.wc_t);
+    w.w2_t = m.depth > 1 ? derp<float>(c, m.w2_t) : nullptr;
+    w.b2 = m.depth > 1 ? rawp(c, m.b[1]) : nullptr;
+    w.depth = m.depth;
+    return w;
+}
+static MpnnWB wbf(rnampnn_ctx* c, const Mlp2& m) {
+    MpnnWB w;
+    w.img = derp<bf16_t>(c, m.img);
+    w.b2p = derp<float>(c, m.b2p);
+    return w;
+}
+
+// one fused step: [edge update with `we`] then [message + aggregation with `wm`]
+static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in, float* h_pre, float* msg_out) {
+    rnampnn_ctx* c = r.c;
+    int k = c->cfg.num_res_neighbours;
+    if (r.fast) {
+        launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.pq_m,
+                         we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_in, h_pre, msg_out, r.s);
+    } else {
+        MpnnW32 e32 = we ? w32(c, *we) : MpnnW32{}, m32 = wm ? w32(c, *wm) : MpnnW32{};
+        launch_mpnn_f32(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (float*)r.w.e, r.w.pq_e, r.w.pq_m, e32, m32,
+                        h_in, h_pre, msg_out, r.s);
+    }
+}
+
+static void unpack_e(Run& r, float* dst) {
+    int k = r.c->cfg.num_res_neighbours;
+    if (r.fast) {
+        launch_bf16_to_f32((const bf16_t*)r.w.e, r.w.big, (size_t)r.pk.Nmax * k * RN_D, r.ntot(), k * RN_D, r.s);
+        launch_unpack_edges(r.pk, k, r.w.big, r.w.nbr, dst, r.s);
+    } else {
+        launch_unpack_edges(r.pk, k, (const float*)r.w.e, r.w.nbr, dst, r.s);
+    }
+}
+
+static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+    if (!h->finalized) return fail(RNAMPNN_ERR_WEIGHTS, "weights not finalized (call rnampnn_finalize_weights)");
+    if (!mask || !ws || B <= 0 || T <= 0) return fail(RNAMPNN_ERR_BAD_ARG, "null pointer or non-positive B/T");
+    if ((long long)B * T > 0x3fffffffLL / (h->cfg.num_res_neighbours * 4))
+        return fail(RNAMPNN_ERR_BAD_ARG, "B*T too large for 32-bit edge indexing; split the batch");
+    size_t need = carve(h, B, T, nullptr, nullptr);
+    if (ws_bytes < need) return fail(RNAMPNN_ERR_WORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, need);
+    if (((uintptr_t)ws & 255) != 0) return fail(RNAMPNN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
+    r.c = h;
+    r.s = (hipStream_t)stream;
+    r.fast = h->cfg.precision == RNAMPNN_PREC_BF16;
+    carve(h, B, T, (char*)ws, &r.w);
+    r.pk.len = r.w.len; r.pk.cu = r.w.cu; r.pk.node_b = r.w.node_b;
+    r.pk.B = B; r.pk.T = T; r.pk.Nmax = B * T;
+    launch_lengths(mask, r.pk, r.s);
+    // the all-zero row Nmax of every gathered node table (phantom neighbour / invalid slot)
+    size_t Nmax = r.pk.Nmax;
+    HIP_TRY(hipMemsetAsync(r.w.hA + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
+    HIP_TRY(hipMemsetAsync(r.w.hB + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
+    HIP_TRY(hipMemsetAsync(r.w.pq_e + Nmax * 256, 0, 256 * sizeof(float), r.s));
+    HIP_TRY(hipMemsetAsync(r.w.pq_m + Nmax * 256, 0, 256 * sizeof(float), r.s));
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, void* ws, size_t ws_bytes, void* stream) {
+    if (!io || !io->coords) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_forward: null io/coords");
+    if (io->stop_after == 0 && !io->logits && !io->embedding)
+        return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_forward: logits (or embedding) output required");
+    Run r;
+    int rc = begin_run(r, h, io->mask, io->B, io->T, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rnampnn_ctx* c = h;
+    const RnaMpnnConfig& g = c->cfg;
+    if (io->T > g.padding_len)
+        return fail(RNAMPNN_ERR_T_GT_P, "max_len %d exceeds padding_len %d", io->T, g.padding_len);
+    int k = g.num_res_neighbours, L = g.num_res_mpnn_layers;
+    int t_norm = io->T_norm > 0 ? io->T_norm : io->T;
+    if (t_norm < io->T) return fail(RNAMPNN_ERR_BAD_ARG, "T_norm %d < T %d", t_norm, io->T);
+    Ws& w = r.w;
+    hipStream_t s = r.s;
+
+    // ---- ResFeature.forward (feature.py:588-592)
+    launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, s);
+    if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
+    if (r.fast)
+        launch_edge_embed_bf16(r.pk, k, w.geom, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
+                               rawp(c, c->edge_embed[1].b), (bf16_t*)w.e, s);
+    else
+        launch_edge_embed_f32(r.pk, k, w.geom, w.nbr, derp<float>(c, c->edge_embed[0].wt), rawp(c, c->edge_embed[0].b),
+                              g.depth_res_edge_feature > 1 ? derp<float>(c, c->edge_embed[1].wt) : nullptr,
+                              g.depth_res_edge_feature > 1 ? rawp(c, c->edge_embed[1].b) : nullptr,
+                              g.depth_res_edge_feature, (float*)w.e, s);
+    gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
+    rc = run_bert(r, c->emb, w.n0, w.n1);
+    if (rc) return rc;
+    launch_graph_norm_packed(r.pk, w.n1, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
+    if (io->h0) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h0, s);
+    if (io->e0) unpack_e(r, io->e0);
+    if (io->stop_after == 1) { HIP_TRY(hipGetLastError()); return RNAMPNN_OK; }
+
+    // ---- L x ResMPNN.forward (mpnn.py:283-294), edge update of layer l fused with the message of l+1
+    node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m);
+    bool edge_pending = false;                                 // layer l-1's edge update not yet applied
+    for (int l = 0; l < L; ++l) {
+        mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr);
+        launch_graph_norm_packed(r.pk, w.hB, w.hA, rawp(c, c->mpnn[l].gn_scale), rawp(c, c->mpnn[l].gn_shift), t_norm, s);
+        bool tap_e = io->tap_layer == l + 1 && io->e_layer;
+        edge_pending = l + 1 < L;                              // layer L's edge update is dead work
+        if (edge_pending || tap_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e);
+        if (l + 1 < L) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m);
+        if (io->tap_layer == l + 1) {
+            if (io->h_layer) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h_layer, s);
+            if (tap_e) {
+                mpnn_step(r, &c->mpnn[l].edge, nullptr, w.hA, w.hB, nullptr);
+                edge_pending = false;
+                unpack_e(r, io->e_layer);
+            }
+        }
+    }
+    // ---- post fusion, raw embedding, readout (rnampnn.py:179-181)
+    rc = run_bert(r, c->post, w.hA, w.n0);                     // h_post -> n0
+    if (rc) return rc;
+    run_ffn(r, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
+    launch_graph_norm_packed(r.pk, w.n1, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
+    if (io->h_post) launch_unpack_nodes(r.pk, w.n0, RN_D, RN_D, io->h_post, s);
+    if (io->raw_emb) launch_unpack_nodes(r.pk, w.n2, RN_D, RN_D, io->raw_emb, s);
+    if (io->embedding) {
+        launch_unpack_nodes_strided(r.pk, w.n0, RN_D, RN_D, io->embedding, 2 * RN_D, 0, s);
+        launch_unpack_nodes_strided(r.pk, w.n2, RN_D, RN_D, io->embedding, 2 * RN_D, RN_D, s);
+    }
+    if (io->logits) {
+        const float* cur = nullptr;
+        int ld = 0;
+        float* bufs[2] = {w.s0, w.s1};
+        for (size_t i = 0; i < c->readout.size(); ++i) {
+            const Lin& l = c->readout[i];
+            bool last = i + 1 == c->readout.size();
+            float* dst = last ? w.logits_p : bufs[i & 1];
+            if (i == 0) gemm(r, l, w.n0, RN_D, dst, l.out, nullptr, 0, w.n2, RN_D, RN_D);   // cat(h_post, raw_emb)
+            else gemm(r, l, cur, ld, dst, l.out);
+            cur = dst; ld = l.out;
+        }
+        launch_unpack_nodes(r.pk, w.logits_p, 4, 4, io->logits, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* h_in, const float* e_in,
+                                  const int64_t* edge_index, const float* mask, int32_t B, int32_t T, int32_t T_norm,
+                                  float* msg_out, float* h_out, float* e_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h_in || !e_in || !edge_index) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_mpnn_layer: null input");
+    Run r;
+    int rc = begin_run(r, h, mask, B, T, ws, ws_bytes, stream);
+    if (rc) return rc;
+    rnampnn_ctx* c = h;
+    if (layer < 0 || layer >= c->cfg.num_res_mpnn_layers) return fail(RNAMPNN_ERR_BAD_ARG, "layer %d out of range", layer);
+    int k = c->cfg.num_res_neighbours;
+    int t_norm = T_norm > 0 ? T_norm : T;
+    Ws& w = r.w;
+    hipStream_t s = r.s;
+    launch_pack_nodes(r.pk, h_in, RN_D, w.hA, RN_D, s);
+    launch_pack_index(r.pk, k, edge_index, w.nbr, s);
+    if (r.fast) {
+        launch_pack_edges(r.pk, k, e_in, w.big, s);
+        launch_f32_to_bf16(w.big, (bf16_t*)w.e, (size_t)r.pk.Nmax * k * RN_D, r.ntot(), k * RN_D, s);
+    } else {
+        launch_pack_edges(r.pk, k, e_in, (float*)w.e, s);
+    }
+    const MpnnLayer& m = c->mpnn[layer];
+    node_pq(r, m.msg, w.hA, w.pq_m);
+    float* msg_p = msg_out ? w.big : nullptr;
+    mpnn_step(r, nullptr, &m.msg, w.hA, w.hB, msg_p);
+    if (msg_out) launch_unpack_edges(r.pk, k, w.big, nullptr, msg_out, s);
+    if (h_out || e_out) {
+        launch_graph_norm_packed(r.pk, w.hB, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
+        if (h_out) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, h_out, s);
+        if (e_out) {
+            node_pq(r, m.edge, w.hA, w.pq_e);
+            mpnn_step(r, &m.edge, nullptr, w.hA, w.hB, nullptr);
+            unpack_e(r, e_out);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_graph_norm(const float* x, const float* mask, const float* scale, const float* shift,
+                                  int32_t B, int32_t T, int32_t T_tot, int32_t D, float* y, void* stream) {
+    if (!x || !mask || !scale || !shift || !y || B <= 0 || T <= 0 || D <= 0)
+        return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_graph_norm: bad argument");
+    if (T_tot <= 0) T_tot = T;
+    if (T_tot < T) return fail(RNAMPNN_ERR_BAD_ARG, "T_tot %d < T %d", T_tot, T);
+    launch_graph_norm_padded(x, mask, scale, shift, B, T, T_tot, D, y, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_rnabert(rnampnn_handle h, int32_t which, const float* x, const float* mask, int32_t B, int32_t T,
+                               float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_rnabert: null tensor");
+    Run r;
+    int rc = begin_run(r, h, mask, B, T, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (T > h->cfg.padding_len) return fail(RNAMPNN_ERR_T_GT_P, "max_len %d exceeds padding_len %d", T, h->cfg.padding_len);
+    launch_pack_nodes(r.pk, x, RN_D, r.w.hA, RN_D, r.s);
+    rc = run_bert(r, which == 0 ? h->emb : h->post, r.w.hA, r.w.n0);
+    if (rc) return rc;
+    launch_unpack_nodes(r.pk, r.w.n0, RN_D, RN_D, y, r.s);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_raw_ffn(rnampnn_handle h, const float* raw, const float* mask, int32_t B, int32_t T, int32_t T_norm,
+                               float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!raw || !y) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_raw_ffn: null tensor");
+    Run r;
+    int rc = begin_run(r, h, mask, B, T, ws, ws_bytes, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(r.w.raw_p, 0, (size_t)r.pk.Nmax * RN_RAWP * sizeof(float), r.s));
+    launch_pack_nodes(r.pk, raw, RN_RAW, r.w.raw_p, RN_RAWP, r.s);
+    run_ffn(r, h->raw_ffn, r.w.raw_p, RN_RAWP, r.w.n1);
+    launch_graph_norm_packed(r.pk, r.w.n1, r.w.n2, rawp(h, h->rawffn_gn_scale), rawp(h, h->rawffn_gn_shift),
+                             T_norm > 0 ? T_norm : T, r.s);
+    launch_unpack_nodes(r.pk, r.w.n2, RN_D, RN_D, y, r.s);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_readout(rnampnn_handle h, const float* emb, const float* mask, int32_t B, int32_t T,
+                               float* logits, void* ws, size_t ws_bytes, void* stream) {
+    if (!emb || !logits) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_readout: null tensor");
+    Run r;
+    int rc = begin_run(r, h, mask, B, T, ws, ws_bytes, stream);
+    if (rc) return rc;
+    Ws& w = r.w;
+    launch_pack_nodes(r.pk, emb, 2 * RN_D, w.pq_e, 2 * RN_D, r.s);
+    const float* cur = w.pq_e;
+    int ld = 2 * RN_D;
+    float* bufs[2] = {w.s0, w.s1};
+    for (size_t i = 0; i < h->readout.size(); ++i) {
+        const Lin& l = h->readout[i];
+        bool last = i + 1 == h->readout.size();
+        float* dst = last ? w.logits_p : bufs[i & 1];
+        gemm(r, l, cur, ld, dst, l.out);
+        cur = dst; ld = l.out;
+    }
+    launch_unpack_nodes(r.pk, w.logits_p, 4, 4, logits, r.s);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_argmax_recovery(const float* logits, const float* mask, const int32_t* labels, int32_t B, int32_t T,
+                                       int8_t* pred, int32_t* correct, int32_t* valid, void* stream) {
+    if (!logits || !mask || B <= 0 || T <= 0) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_argmax_recovery: bad argument");
+    launch_argmax_recovery(logits, mask, labels, B, T, pred, correct, valid, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_sample(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
+                              int32_t n_samples, uint64_t seed, int8_t* out, void* stream) {
+    if (!logits || !mask || !out || B <= 0 || T <= 0 || n_samples <= 0)
+        return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_sample: bad argument");
+    if (!(temperature > 0.f)) return fail(RNAMPNN_ERR_BAD_ARG, "temperature must be > 0");
+    launch_sample(logits, mask, B, T, temperature, n_samples, seed, out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}

@@ -1,0 +1,842 @@
+// Exact-f32 kernels of the RNA-MPNN forward path for gfx950 (wave64).
+// These are the parity-grade kernels (|dlogit| <= 1e-4 vs the oracle): plain f32 FMA
+// arithmetic, LDS-staged operand tiles, one 256-thread workgroup per 32-row tile.
+// The bf16/MFMA kernels in kernels_bf16.hip replace the GEMM-shaped ones on the fast path;
+// the graph / geometry / normalisation / decode kernels here serve both precisions.
+// Reference lines restated by each kernel are cited at its head.
+#include "rnampnn_internal.h"
+
+#define WAVE 64
+static constexpr float kLEPS = 1.0e6f;
+static constexpr float kSEPS = 1.0e-6f;
+
+__device__ __forceinline__ float gelu_erf(float x) {           // nn.GELU() default (erf form)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// lengths + prefix sum of the prefix masks produced by the reference collate
+// (rnampnn/utils/data.py:128-139).
+__global__ void k_lengths(const float* __restrict__ mask, int B, int T, int* __restrict__ len) {
+    int b = blockIdx.x;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += WAVE) s += mask[(size_t)b * T + t];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) len[b] = (int)(s + 0.5f);
+}
+
+__global__ void __launch_bounds__(1024) k_scan(const int* __restrict__ len, int B, int* __restrict__ cu) {
+    __shared__ int part[1024];
+    int tid = threadIdx.x;
+    int chunk = (B + 1023) / 1024;
+    int lo = tid * chunk, hi = min(B, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += len[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { int v = part[i]; part[i] = run; run += v; }
+        cu[B] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) { cu[i] = run; run += len[i]; }
+}
+
+void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s) {
+    hipLaunchKernelGGL(k_lengths, dim3(pk.B), dim3(WAVE), 0, s, mask, pk.B, pk.T, pk.len);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pk.len, pk.B, pk.cu);
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-residue geometry: the 28 raw node features (feature.py:298-384, 531-535) and the
+// record the edge kernels gather per neighbour: 21 coordinates, 5 unit bond vectors
+// (F.normalize eps 1e-12, feature.py:455-456), 4 unit plane normals (cross of consecutive
+// raw bond vectors, eps 1e-6, feature.py:496-505).  One thread per (b, t); t == n_b also
+// fills the record of the RNA's phantom neighbour (row Nmax + b), see k_knn.
+__device__ __forceinline__ void geom_record(const float* c, float* g) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) g[i] = c[i];
+    float v[5][3];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[a][d] = c[(a + 1) * 3 + d] - c[a * 3 + d];
+        float nr = sqrtf(v[a][0] * v[a][0] + v[a][1] * v[a][1] + v[a][2] * v[a][2]);
+        float inv = 1.0f / fmaxf(nr, 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[21 + a * 3 + d] = v[a][d] * inv;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float x = v[a][1] * v[a + 1][2] - v[a][2] * v[a + 1][1];
+        float y = v[a][2] * v[a + 1][0] - v[a][0] * v[a + 1][2];
+        float z = v[a][0] * v[a + 1][1] - v[a][1] * v[a + 1][0];
+        float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), kSEPS);
+        g[36 + a * 3 + 0] = x * inv; g[36 + a * 3 + 1] = y * inv; g[36 + a * 3 + 2] = z * inv;
+    }
+}
+
+__device__ __forceinline__ void raw_features(const float* c, float* f) {
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 7; ++b) {                       // triu(offset=1), row-major (feature.py:322-325)
+            float dx = c[a * 3] - c[b * 3], dy = c[a * 3 + 1] - c[b * 3 + 1], dz = c[a * 3 + 2] - c[b * 3 + 2];
+            f[o++] = sqrtf(dx * dx + dy * dy + dz * dz + kSEPS);
+        }
+    float v[5][3], nr[5], u[5][3];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[a][d] = c[(a + 1) * 3 + d] - c[a * 3 + d];
+        nr[a] = sqrtf(v[a][0] * v[a][0] + v[a][1] * v[a][1] + v[a][2] * v[a][2]);
+        float inv = 1.0f / fmaxf(nr[a], kSEPS);                // F.normalize(eps=SEPS) feature.py:377
+#pragma unroll
+        for (int d = 0; d < 3; ++d) u[a][d] = v[a][d] * inv;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)                                 // feature.py:351-355
+        f[21 + a] = (v[a][0] * v[a + 1][0] + v[a][1] * v[a + 1][1] + v[a][2] * v[a + 1][2]) / (nr[a] * nr[a + 1] + kSEPS);
+    float nm[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                               // feature.py:381
+        float x = u[a][1] * u[a + 1][2] - u[a][2] * u[a + 1][1];
+        float y = u[a][2] * u[a + 1][0] - u[a][0] * u[a + 1][2];
+        float z = u[a][0] * u[a + 1][1] - u[a][1] * u[a + 1][0];
+        float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), kSEPS);
+        nm[a][0] = x * inv; nm[a][1] = y * inv; nm[a][2] = z * inv;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) f[25 + a] = nm[a + 1][0] * nm[a][0] + nm[a + 1][1] * nm[a][1] + nm[a + 1][2] * nm[a][2];
+}
+
+__global__ void k_geom(const float* __restrict__ coords, PackInfo pk, float* __restrict__ raw_out,
+                       float* __restrict__ raw_p, float* __restrict__ geom) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= pk.B * pk.T) return;
+    int b = id / pk.T, t = id - b * pk.T;
+    int n = pk.len[b];
+    float c[21];
+    const float* src = coords + (size_t)id * 21;
+#pragma unroll
+    for (int i = 0; i < 21; ++i) c[i] = src[i];
+    if (t < n) {
+        int p = pk.cu[b] + t;
+        pk.node_b[p] = b;
+        float f[28];
+        raw_features(c, f);
+        float* rp = raw_p + (size_t)p * RN_RAWP;
+#pragma unroll
+        for (int i = 0; i < 28; ++i) rp[i] = f[i];
+#pragma unroll
+        for (int i = 28; i < RN_RAWP; ++i) rp[i] = 0.f;
+        if (raw_out) {
+            float* ro = raw_out + (size_t)id * RN_RAW;
+#pragma unroll
+            for (int i = 0; i < 28; ++i) ro[i] = f[i];
+        }
+        float g[RN_GEOM];
+        geom_record(c, g);
+        float* gp = geom + (size_t)p * RN_GEOM;
+#pragma unroll
+        for (int i = 0; i < RN_GEOM; ++i) gp[i] = g[i];
+    } else {
+        if (raw_out) {                                          // padded rows: 1e6 distances, 0 cosines
+            float* ro = raw_out + (size_t)id * RN_RAW;
+#pragma unroll
+            for (int i = 0; i < 21; ++i) ro[i] = kLEPS;
+#pragma unroll
+            for (int i = 21; i < 28; ++i) ro[i] = 0.f;
+        }
+        if (t == n) {                                           // phantom neighbour of RNA b
+            float g[RN_GEOM];
+            geom_record(c, g);
+            float* gp = geom + (size_t)(pk.Nmax + b) * RN_GEOM;
+#pragma unroll
+            for (int i = 0; i < RN_GEOM; ++i) gp[i] = g[i];
+        }
+    }
+}
+
+void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, hipStream_t s) {
+    int total = pk.B * pk.T;
+    hipLaunchKernelGGL(k_geom, dim3((total + 63) / 64), dim3(64), 0, s, coords, pk, raw_out, raw_p, geom);
+}
+
+// ------------------------------------------------------------------------------------------
+// k-NN graph over residue centroids (feature.py:205-256).  One wave per row: the row of
+// distances d(i, j) = sqrt(|c_i - c_j|^2 + 1e-6) lives in LDS, and the min(k, n-1) nearest
+// residues are extracted in ascending (distance, index) order by k wave-wide min-reductions
+// of a packed 64-bit key.  Self and padded residues all sit at exactly 1e6 in the reference
+// and are never real neighbours.  Slot n-1 (when n-1 < k): the reference keeps one extra edge
+// to a PADDED residue iff T > n -> the phantom neighbour (index n in the
+// API tensor, row Nmax + b in the packed index); all later slots are -1.
+__global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, PackInfo pk, int k, int rows_per_block,
+                                              int* __restrict__ nbr, int64_t* __restrict__ eidx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    int b = blockIdx.x;
+    int n = pk.len[b];
+    int T = pk.T;
+    int row0 = blockIdx.y * rows_per_block;
+    if (row0 >= T) return;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* cen = sm;                       // [T][3]
+    float* drow = sm + 3 * T + w * T;      // per-wave distance row
+    if (row0 < n) {
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const float* c = coords + ((size_t)b * T + j) * 21;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) { sx += c[a * 3]; sy += c[a * 3 + 1]; sz += c[a * 3 + 2]; }
+            cen[j * 3] = sx / 7.0f; cen[j * 3 + 1] = sy / 7.0f; cen[j * 3 + 2] = sz / 7.0f;
+        }
+    }
+    __syncthreads();
+    int base = pk.cu[b];
+    for (int i = row0 + w; i < min(T, row0 + rows_per_block); i += 4) {
+        if (i >= n) {                                           // padded row: all -1 (feature.py:253-254)
+            if (eidx) for (int s = lane; s < k; s += 64) eidx[((size_t)b * T + i) * k + s] = -1;
+            continue;
+        }
+        float cx = cen[i * 3], cy = cen[i * 3 + 1], cz = cen[i * 3 + 2];
+        for (int j = lane; j < n; j += 64) {
+            float dx = __fsub_rn(cen[j * 3], cx), dy = __fsub_rn(cen[j * 3 + 1], cy), dz = __fsub_rn(cen[j * 3 + 2], cz);
+            float ss = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            drow[j] = (j == i) ? 3.0e38f : sqrtf(__fadd_rn(ss, kSEPS));
+        }
+        // (wave-private LDS row: same-wave accesses are program ordered)
+        int nreal = min(k, n - 1);
+        unsigned long long prev = 0ull;                         // keys are > 0 (distance >= 1e-3)
+        size_t pbase = (size_t)(base + i) * k;
+        size_t obase = ((size_t)b * T + i) * k;
+        for (int s = 0; s < nreal; ++s) {
+            unsigned long long best = ~0ull;
+            for (int j = lane; j < n; j += 64) {
+                unsigned long long key = ((unsigned long long)__float_as_uint(drow[j]) << 32) | (unsigned)j;
+                if (key > prev && key < best) best = key;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                unsigned long long other = __shfl_xor(best, o, 64);
+                best = other < best ? other : best;
+            }
+            prev = best;
+            if (lane == 0) {
+                int j = (int)(best & 0xffffffffu);
+                nbr[pbase + s] = base + j;
+                if (eidx) eidx[obase + s] = j;
+            }
+        }
+        for (int s = nreal + lane; s < k; s += 64) {
+            bool phantom = (s == n - 1) && (n < T);
+            nbr[pbase + s] = phantom ? pk.Nmax + b : -1;
+            if (eidx) eidx[obase + s] = phantom ? n : -1;
+        }
+    }
+}
+
+int launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t* eidx, hipStream_t s) {
+    size_t lds = (size_t)(3 + 4) * pk.T * sizeof(float);
+    if (lds > 160 * 1024 - 256) return 1;                       // T too long for the LDS-resident row
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int rpb = pk.T <= 512 ? 16 : 64;
+    dim3 grid(pk.B, (pk.T + rpb - 1) / rpb);
+    hipLaunchKernelGGL(k_knn, grid, dim3(256), lds, s, coords, pk, k, rpb, nbr, eidx);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// 32 x 128 tile of a Linear layer on 256 threads: thread (c = tid & 127, g = tid >> 7) owns
+// column c of rows g*16 .. g*16+15.  X tile in LDS (row stride ldx floats), weights K-major in
+// HBM/L2 (coalesced across c).  All lanes of a wave share g, so X reads are LDS broadcasts.
+__device__ __forceinline__ void tile_fma(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ Wt,
+                                         int ldw, int c, int g, float (&acc)[16]) {
+    const float* xr = Xs + g * 16 * ldx;
+    for (int kk = 0; kk < K; kk += 4) {
+        float w0 = Wt[(size_t)(kk + 0) * ldw + c], w1 = Wt[(size_t)(kk + 1) * ldw + c];
+        float w2 = Wt[(size_t)(kk + 2) * ldw + c], w3 = Wt[(size_t)(kk + 3) * ldw + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 x = *reinterpret_cast<const float4*>(xr + r * ldx + kk);
+            acc[r] = fmaf(x.x, w0, acc[r]); acc[r] = fmaf(x.y, w1, acc[r]);
+            acc[r] = fmaf(x.z, w2, acc[r]); acc[r] = fmaf(x.w, w3, acc[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge featurisation + edge-embedding MLP (feature.py:386-571).  One workgroup per residue:
+// thread s < k computes the 90 raw features of edge (p, s) from the two geometry records
+// (49 distances a*7+b, 25 bond cosines a*5+b, 16 normal cosines a*4+b) into LDS - the
+// 90-wide tensor never reaches HBM - then Linear(90,128)+GELU [+ Linear(128,128)+GELU].
+// Invalid slots (nbr == -1) give e = 0 (feature.py:564-569).
+#define EX_LD 100   // 96 + 4 pad (keeps float4 alignment, staggers banks)
+#define EH_LD 132
+__global__ void __launch_bounds__(256) k_edge_embed_f32(PackInfo pk, int k, const float* __restrict__ geom,
+        const int* __restrict__ nbr, const float* __restrict__ w0t, const float* __restrict__ b0,
+        const float* __restrict__ w1t, const float* __restrict__ b1, int depth, float* __restrict__ e) {
+    __shared__ __attribute__((aligned(16))) float X[32 * EX_LD];
+    __shared__ __attribute__((aligned(16))) float H[32 * EH_LD];
+    __shared__ int valid_s[32];
+    int ntot = pk.cu[pk.B];
+    for (int p = blockIdx.x; p < ntot; p += gridDim.x) {
+        int tid = threadIdx.x;
+        if (tid < 32) {
+            int j = (tid < k) ? nbr[(size_t)p * k + tid] : -1;
+            valid_s[tid] = j >= 0;
+            float* x = X + tid * EX_LD;
+            if (j >= 0) {
+                const float* gi = geom + (size_t)p * RN_GEOM;
+                const float* gj = geom + (size_t)j * RN_GEOM;
+                float cj[RN_GEOM];
+#pragma unroll
+                for (int i = 0; i < RN_GEOM; ++i) cj[i] = gj[i];
+#pragma unroll
+                for (int a = 0; a < 7; ++a) {
+                    float ax = gi[a * 3], ay = gi[a * 3 + 1], az = gi[a * 3 + 2];
+#pragma unroll
+                    for (int bb = 0; bb < 7; ++bb) {
+                        float dx = ax - cj[bb * 3], dy = ay - cj[bb * 3 + 1], dz = az - cj[bb * 3 + 2];
+                        x[a * 7 + bb] = sqrtf(dx * dx + dy * dy + dz * dz + kSEPS);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    float ax = gi[21 + a * 3], ay = gi[22 + a * 3], az = gi[23 + a * 3];
+#pragma unroll
+                    for (int bb = 0; bb < 5; ++bb)
+                        x[49 + a * 5 + bb] = ax * cj[21 + bb * 3] + ay * cj[22 + bb * 3] + az * cj[23 + bb * 3];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float ax = gi[36 + a * 3], ay = gi[37 + a * 3], az = gi[38 + a * 3];
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb)
+                        x[74 + a * 4 + bb] = ax * cj[36 + bb * 3] + ay * cj[37 + bb * 3] + az * cj[38 + bb * 3];
+                }
+#pragma unroll
+                for (int i = RN_ERAW; i < RN_ERAWP; ++i) x[i] = 0.f;
+            } else {
+                for (int i = 0; i < RN_ERAWP; ++i) x[i] = 0.f;
+            }
+        }
+        __syncthreads();
+        int c = tid & 127, g = tid >> 7;
+        float acc[16];
+        float bias = b0[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        tile_fma(X, EX_LD, RN_ERAWP, w0t, RN_D, c, g, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+        if (depth > 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H[(g * 16 + r) * EH_LD + c] = acc[r];
+            __syncthreads();
+            bias = b1[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias;
+            tile_fma(H, EH_LD, RN_D, w1t, RN_D, c, g, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int s = g * 16 + r;
+            if (s < k) e[((size_t)p * k + s) * RN_D + c] = valid_s[s] ? acc[r] : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_edge_embed_f32(const PackInfo& pk, int k, const float* geom, const int* nbr, const float* w0t,
+                           const float* b0, const float* w1t, const float* b1, int depth, float* e, hipStream_t s) {
+    int grid = pk.Nmax < 4096 ? pk.Nmax : 4096;
+    hipLaunchKernelGGL(k_edge_embed_f32, dim3(grid), dim3(256), 0, s, pk, k, geom, nbr, w0t, b0, w1t, b1, depth, e);
+}
+
+// ------------------------------------------------------------------------------------------
+// One ResMPNN step on the k edges of one residue (mpnn.py:154-265), f32.
+// The first Linear of both MLPs acts on cat[h_i, h_j, e] (mpnn.py:184-188, 260); it is
+// evaluated as P[i] + Q[j] + e.Wc with P = h.Wa^T + b1 and Q = h.Wb^T computed once per
+// residue by the node GEMM (pq_* rows are [P | Q], 256 wide) - identical mathematics,
+// different summation order.  DO_EDGE: e <- e + MLP_e(...) (mpnn.py:263; invalid slots stay
+// 0, the reference leaves never-consumed garbage there).  DO_MSG: messages, masked mean over
+// the valid slots, residual: h_pre = h + sum/max(cnt,1) (mpnn.py:191-225).
+template <bool DO_EDGE, bool DO_MSG>
+__global__ void __launch_bounds__(256) k_mpnn_f32(PackInfo pk, int k, const int* __restrict__ nbr, float* __restrict__ e,
+        const float* __restrict__ pq_e, const float* __restrict__ pq_m, MpnnW32 we, MpnnW32 wm,
+        const float* __restrict__ h_in, float* __restrict__ h_pre, float* __restrict__ msg_out) {
+    __shared__ __attribute__((aligned(16))) float X[32 * EH_LD];
+    __shared__ __attribute__((aligned(16))) float H[32 * EH_LD];
+    __shared__ int jrow[32];
+    __shared__ float part[128];
+    int ntot = pk.cu[pk.B];
+    int tid = threadIdx.x, c = tid & 127, g = tid >> 7;
+    for (int p = blockIdx.x; p < ntot; p += gridDim.x) {
+        if (tid < 32) jrow[tid] = (tid < k) ? nbr[(size_t)p * k + tid] : -1;
+        for (int idx = tid; idx < 32 * 32; idx += 256) {        // e rows -> LDS (float4 per thread)
+            int r = idx >> 5, q = idx & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < k) v = *reinterpret_cast<const float4*>(e + ((size_t)p * k + r) * RN_D + q * 4);
+            *reinterpret_cast<float4*>(X + r * EH_LD + q * 4) = v;
+        }
+        __syncthreads();
+        float acc[16];
+        if (DO_EDGE) {
+            float pi = pq_e[(size_t)p * 256 + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int j = jrow[g * 16 + r];
+                j = j < 0 ? 0 : (j > pk.Nmax ? pk.Nmax : j);    // phantom -> the all-zero row Nmax
+                acc[r] = pi + pq_e[(size_t)j * 256 + 128 + c];
+            }
+            tile_fma(X, EH_LD, RN_D, we.wc_t, RN_D, c, g, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+            if (we.depth > 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) H[(g * 16 + r) * EH_LD + c] = acc[r];
+                __syncthreads();
+                float bias = we.b2[c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bias;
+                tile_fma(H, EH_LD, RN_D, we.w2_t, RN_D, c, g, acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+            } else {
+                __syncthreads();
+            }
+            // every thread has finished reading X for the first Linear (barrier above)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int s = g * 16 + r;
+                if (s < k && jrow[s] >= 0) {
+                    float v = X[s * EH_LD + c] + acc[r];
+                    X[s * EH_LD + c] = v;
+                    e[((size_t)p * k + s) * RN_D + c] = v;
+                }
+            }
+            __syncthreads();
+        }
+        if (DO_MSG) {
+            float pi = pq_m[(size_t)p * 256 + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int j = jrow[g * 16 + r];
+                j = j < 0 ? 0 : (j > pk.Nmax ? pk.Nmax : j);
+                acc[r] = pi + pq_m[(size_t)j * 256 + 128 + c];
+            }
+            tile_fma(X, EH_LD, RN_D, wm.wc_t, RN_D, c, g, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+            if (wm.depth > 1) {
+                __syncthreads();                                 // H may still be read by the edge MLP
+#pragma unroll
+                for (int r = 0; r < 16; ++r) H[(g * 16 + r) * EH_LD + c] = acc[r];
+                __syncthreads();
+                float bias = wm.b2[c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bias;
+                tile_fma(H, EH_LD, RN_D, wm.w2_t, RN_D, c, g, acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = gelu_erf(acc[r]);
+            }
+            float sum = 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int s = g * 16 + r;
+                bool ok = s < k && jrow[s] >= 0;
+                float m = ok ? acc[r] : 0.f;
+                sum += m;
+                if (msg_out && s < k) msg_out[((size_t)p * k + s) * RN_D + c] = m;
+            }
+            for (int s = 0; s < k; ++s) cnt += jrow[s] >= 0;
+            if (g == 1) part[c] = sum;
+            __syncthreads();
+            if (g == 0) {
+                float tot = sum + part[c];
+                float denom = (float)(cnt > 0 ? cnt : 1);
+                h_pre[(size_t)p * RN_D + c] = h_in[(size_t)p * RN_D + c] + tot / denom;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_mpnn_f32(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, float* e,
+                     const float* pq_e, const float* pq_m, MpnnW32 we, MpnnW32 wm, const float* h_in,
+                     float* h_pre, float* msg_out, hipStream_t s) {
+    int grid = pk.Nmax < 4096 ? pk.Nmax : 4096;
+    if (do_edge && do_msg)
+        hipLaunchKernelGGL((k_mpnn_f32<true, true>), dim3(grid), dim3(256), 0, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
+    else if (do_edge)
+        hipLaunchKernelGGL((k_mpnn_f32<true, false>), dim3(grid), dim3(256), 0, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
+    else
+        hipLaunchKernelGGL((k_mpnn_f32<false, true>), dim3(grid), dim3(256), 0, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// GraphNormalization on packed rows (functional.py:18-48), D = 128, one workgroup per RNA:
+//   mu = sum_valid x / n ;  var = [sum_valid (x-mu)^2 + (T_tot - n) mu^2] / n
+//   y = (x - mu) / sqrt(var + 1e-6) * scale + shift         (padded rows do not exist here)
+__global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const float* __restrict__ x, float* __restrict__ y,
+        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot) {
+    __shared__ float red[256];
+    int b = blockIdx.x;
+    int n = pk.len[b];
+    if (n <= 0) return;
+    int base = pk.cu[b];
+    int c = threadIdx.x & 127, hf = threadIdx.x >> 7;
+    const float* xb = x + (size_t)base * RN_D;
+    float s = 0.f;
+    for (int r = hf; r < n; r += 2) s += xb[(size_t)r * RN_D + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    float mean = (red[c] + red[c + 128]) / (float)n;
+    __syncthreads();
+    float ss = 0.f;
+    for (int r = hf; r < n; r += 2) { float d = xb[(size_t)r * RN_D + c] - mean; ss = fmaf(d, d, ss); }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    float var = (red[c] + red[c + 128] + (float)(t_tot - n) * mean * mean) / (float)n;
+    float sd = sqrtf(var + kSEPS);
+    float sc = scale[c], sh = shift[c];
+    float* yb = y + (size_t)base * RN_D;
+    for (int r = hf; r < n; r += 2) yb[(size_t)r * RN_D + c] = (xb[(size_t)r * RN_D + c] - mean) / sd * sc + sh;
+}
+
+void launch_graph_norm_packed(const PackInfo& pk, const float* x, float* y, const float* scale, const float* shift,
+                              int t_tot, hipStream_t s) {
+    hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, y, scale, shift, t_tot);
+}
+
+// Stand-alone GraphNormalization on the reference's padded layout, any D, mask by value.
+__global__ void __launch_bounds__(256) k_graph_norm_padded(const float* __restrict__ x, const float* __restrict__ mask,
+        const float* __restrict__ scale, const float* __restrict__ shift, int T, int t_tot, int D, float* __restrict__ y) {
+    int b = blockIdx.x;
+    const float* xb = x + (size_t)b * T * D;
+    const float* mb = mask + (size_t)b * T;
+    float* yb = y + (size_t)b * T * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float cnt = 0.f, s = 0.f;
+        for (int t = 0; t < T; ++t) { float m = mb[t]; cnt += m; s += xb[(size_t)t * D + c] * m; }
+        float n = cnt == 0.f ? 1.f : cnt;
+        float mean = s / n;
+        float ss = 0.f;
+        for (int t = 0; t < T; ++t) { float d = xb[(size_t)t * D + c] * mb[t] - mean; ss = fmaf(d, d, ss); }
+        ss += (float)(t_tot - T) * mean * mean;
+        float sd = sqrtf(ss / n + kSEPS);
+        float sc = scale[c], sh = shift[c];
+        for (int t = 0; t < T; ++t) yb[(size_t)t * D + c] = ((xb[(size_t)t * D + c] - mean) / sd * sc + sh) * mb[t];
+    }
+}
+
+void launch_graph_norm_padded(const float* x, const float* mask, const float* scale, const float* shift, int B, int T,
+                              int t_tot, int D, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(k_graph_norm_padded, dim3(B), dim3(256), 0, s, x, mask, scale, shift, T, t_tot, D, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic node-level Linear on packed rows: Y = act([X | X2] . Wt + bias) (+ res).
+// 32 x 128 output tile per workgroup, K staged through LDS in chunks of 128.
+__global__ void __launch_bounds__(256) k_gemm_f32(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx, int K1,
+        const float* __restrict__ X2, int ldx2, int K2, const float* __restrict__ Wt, const float* __restrict__ bias,
+        int N, int act, const float* __restrict__ res, int ldres, float* __restrict__ Y, int ldy) {
+    __shared__ __attribute__((aligned(16))) float Xs[32 * EH_LD];
+    int ntot = *ntot_p;
+    int row0 = blockIdx.x * 32;
+    if (row0 >= ntot) return;
+    int col0 = blockIdx.y * 128;
+    int tid = threadIdx.x, c = tid & 127, g = tid >> 7;
+    int cc = col0 + c;
+    int cw = cc < N ? cc : N - 1;                               // clamp: out-of-range columns compute and drop
+    float acc[16];
+    float bv = bias ? bias[cw] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    int K = K1 + K2;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        int kc = min(128, K - k0);                              // multiple of 4 by construction
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            int r = idx >> 5, q = idx & 31;
+            int kk = k0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int row = row0 + r;
+            if (row < ntot && q * 4 < kc) {
+                if (kk < K1) v = *reinterpret_cast<const float4*>(X + (size_t)row * ldx + kk);
+                else v = *reinterpret_cast<const float4*>(X2 + (size_t)row * ldx2 + (kk - K1));
+            }
+            *reinterpret_cast<float4*>(Xs + r * EH_LD + q * 4) = v;
+        }
+        __syncthreads();
+        tile_fma(Xs, EH_LD, kc, Wt + (size_t)k0 * N + cw - c, N, c, g, acc);
+        __syncthreads();
+    }
+    if (cc < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = row0 + g * 16 + r;
+            if (row < ntot) {
+                float v = acc[r];
+                if (act == 1) v = gelu_erf(v);
+                if (res) v += res[(size_t)row * ldres + cc];
+                Y[(size_t)row * ldy + cc] = v;
+            }
+        }
+    }
+}
+
+void launch_gemm_f32(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
+                     const float* Wt, const float* bias, int N, int act, const float* res, int ldres,
+                     float* Y, int ldy, hipStream_t s) {
+    dim3 grid((mmax + 31) / 32, (N + 127) / 128);
+    hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, Wt, bias, N, act, res, ldres, Y, ldy);
+}
+
+// ------------------------------------------------------------------------------------------
+// nn.MultiheadAttention forward over the VALID keys of one RNA (functional.py:164-168):
+// qkv rows are [q | k | v] (3 x 128) after the in-projection; one thread per query, keys
+// staged through LDS in chunks of 64, online softmax.  Padded keys are masked in the
+// reference and padded queries are discarded, so neither exists here.
+template <int HD>
+__global__ void __launch_bounds__(64) k_attention_f32(PackInfo pk, const float* __restrict__ qkv, int heads,
+                                                     float* __restrict__ out) {
+    __shared__ float Ks[64 * HD];
+    __shared__ float Vs[64 * HD];
+    int b = blockIdx.x, hd = blockIdx.y;
+    int n = pk.len[b];
+    int q0 = blockIdx.z * 64;
+    if (q0 >= n) return;
+    int base = pk.cu[b];
+    int qi = q0 + threadIdx.x;
+    bool active = qi < n;
+    float q[HD], acc[HD];
+    float scale = rsqrtf((float)HD);
+    const float* qp = qkv + (size_t)(base + (active ? qi : 0)) * 384 + hd * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qp[d] * scale; acc[d] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        int kn = min(64, n - k0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kn * HD; idx += 64) {
+            int r = idx / HD, d = idx - r * HD;
+            const float* row = qkv + (size_t)(base + k0 + r) * 384 + hd * HD + d;
+            Ks[idx] = row[128];
+            Vs[idx] = row[256];
+        }
+        __syncthreads();
+        for (int j = 0; j < kn; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc = fmaf(q[d], Ks[j * HD + d], sc);
+            float mn = fmaxf(m, sc);
+            float corr = __expf(m - mn), pj = __expf(sc - mn);
+            l = l * corr + pj;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(pj, Vs[j * HD + d], acc[d] * corr);
+            m = mn;
+        }
+    }
+    if (active) {
+        float inv = 1.0f / l;
+        float* op = out + (size_t)(base + qi) * RN_D + hd * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+    }
+}
+
+int launch_attention_f32(const PackInfo& pk, const float* qkv, int heads, float* out, hipStream_t s) {
+    dim3 grid(pk.B, heads, (pk.T + 63) / 64);
+    int hd = RN_D / heads;
+    if (hd == 16) hipLaunchKernelGGL(k_attention_f32<16>, grid, dim3(64), 0, s, pk, qkv, heads, out);
+    else if (hd == 32) hipLaunchKernelGGL(k_attention_f32<32>, grid, dim3(64), 0, s, pk, qkv, heads, out);
+    else if (hd == 8) hipLaunchKernelGGL(k_attention_f32<8>, grid, dim3(64), 0, s, pk, qkv, heads, out);
+    else if (hd == 64) hipLaunchKernelGGL(k_attention_f32<64>, grid, dim3(64), 0, s, pk, qkv, heads, out);
+    else return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// pack / unpack between the reference's padded layouts and the packed rows.
+__global__ void k_unpack_nodes(PackInfo pk, const float* __restrict__ src, int ld, int D, float* __restrict__ dst,
+                               int dst_ld, int dst_col0) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)pk.B * pk.T * D;
+    if (id >= total) return;
+    int d = (int)(id % D);
+    size_t bt = id / D;
+    int b = (int)(bt / pk.T), t = (int)(bt - (size_t)b * pk.T);
+    dst[bt * dst_ld + dst_col0 + d] = t < pk.len[b] ? src[(size_t)(pk.cu[b] + t) * ld + d] : 0.f;
+}
+void launch_unpack_nodes_strided(const PackInfo& pk, const float* src, int ld, int D, float* dst, int dst_ld,
+                                 int dst_col0, hipStream_t s) {
+    size_t total = (size_t)pk.B * pk.T * D;
+    hipLaunchKernelGGL(k_unpack_nodes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pk, src, ld, D, dst, dst_ld, dst_col0);
+}
+void launch_unpack_nodes(const PackInfo& pk, const float* src, int ld, int D, float* dst, hipStream_t s) {
+    launch_unpack_nodes_strided(pk, src, ld, D, dst, D, 0, s);
+}
+
+__global__ void k_pack_nodes(PackInfo pk, const float* __restrict__ src, int D, float* __restrict__ dst, int ld) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)pk.B * pk.T * D;
+    if (id >= total) return;
+    int d = (int)(id % D);
+    size_t bt = id / D;
+    int b = (int)(bt / pk.T), t = (int)(bt - (size_t)b * pk.T);
+    if (t < pk.len[b]) {
+        dst[(size_t)(pk.cu[b] + t) * ld + d] = src[id];
+        if (d == 0) pk.node_b[pk.cu[b] + t] = b;
+    }
+}
+void launch_pack_nodes(const PackInfo& pk, const float* src, int D, float* dst, int ld, hipStream_t s) {
+    size_t total = (size_t)pk.B * pk.T * D;
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pk, src, D, dst, ld);
+}
+
+// edges: (B,T,k,128) <-> packed (N_tot*k, 128); invalid slots and padded rows unpack to 0.
+__global__ void k_unpack_edges(PackInfo pk, int k, const float* __restrict__ src, const int* __restrict__ nbr,
+                               float* __restrict__ dst) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread
+    size_t total = (size_t)pk.B * pk.T * k * 32;
+    if (id >= total) return;
+    int q = (int)(id & 31);
+    size_t row = id >> 5;
+    int sl = (int)(row % k);
+    size_t bt = row / k;
+    int b = (int)(bt / pk.T), t = (int)(bt - (size_t)b * pk.T);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < pk.len[b]) {
+        size_t pe = (size_t)(pk.cu[b] + t) * k + sl;
+        if (!nbr || nbr[pe] >= 0) v = *reinterpret_cast<const float4*>(src + pe * RN_D + q * 4);
+    }
+    *reinterpret_cast<float4*>(dst + row * RN_D + q * 4) = v;
+}
+void launch_unpack_edges(const PackInfo& pk, int k, const float* src, const int* nbr, float* dst, hipStream_t s) {
+    size_t total = (size_t)pk.B * pk.T * k * 32;
+    hipLaunchKernelGGL(k_unpack_edges, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pk, k, src, nbr, dst);
+}
+
+__global__ void k_pack_edges(PackInfo pk, int k, const float* __restrict__ src, float* __restrict__ dst) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)pk.B * pk.T * k * 32;
+    if (id >= total) return;
+    int q = (int)(id & 31);
+    size_t row = id >> 5;
+    int sl = (int)(row % k);
+    size_t bt = row / k;
+    int b = (int)(bt / pk.T), t = (int)(bt - (size_t)b * pk.T);
+    if (t < pk.len[b]) {
+        size_t pe = (size_t)(pk.cu[b] + t) * k + sl;
+        *reinterpret_cast<float4*>(dst + pe * RN_D + q * 4) = *reinterpret_cast<const float4*>(src + row * RN_D + q * 4);
+    }
+}
+void launch_pack_edges(const PackInfo& pk, int k, const float* src, float* dst, hipStream_t s) {
+    size_t total = (size_t)pk.B * pk.T * k * 32;
+    hipLaunchKernelGGL(k_pack_edges, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pk, k, src, dst);
+}
+
+// edge_index (B,T,k) i64, local indices / -1  ->  packed global rows; any padded index (>= n_b)
+// is the phantom neighbour (zero embedding) of that RNA.
+__global__ void k_pack_index(PackInfo pk, int k, const int64_t* __restrict__ eidx, int* __restrict__ nbr) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)pk.B * pk.T * k;
+    if (id >= total) return;
+    int sl = (int)(id % k);
+    size_t bt = id / k;
+    int b = (int)(bt / pk.T), t = (int)(bt - (size_t)b * pk.T);
+    int n = pk.len[b];
+    if (t < n) {
+        long long j = eidx[id];
+        int v = j < 0 ? -1 : (j >= n ? pk.Nmax + b : pk.cu[b] + (int)j);
+        nbr[(size_t)(pk.cu[b] + t) * k + sl] = v;
+    }
+}
+void launch_pack_index(const PackInfo& pk, int k, const int64_t* eidx, int* nbr, hipStream_t s) {
+    size_t total = (size_t)pk.B * pk.T * k;
+    hipLaunchKernelGGL(k_pack_index, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pk, k, eidx, nbr);
+}
+
+__global__ void k_transpose(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst, int ld_dst) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= rows * cols) return;
+    int r = id / cols, c = id - r * cols;
+    dst[(size_t)c * ld_dst + r] = src[(size_t)r * ld_src + c];
+}
+void launch_transpose(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {
+    int total = rows * cols;
+    hipLaunchKernelGGL(k_transpose, dim3((total + 255) / 256), dim3(256), 0, s, src, ld_src, rows, cols, dst, ld_dst);
+}
+
+// ------------------------------------------------------------------------------------------
+// decode: argmax + recovery counts (rnampnn.py:223-230; argmax of softmax = argmax of logits,
+// first maximum wins as torch.argmax does), one wave per RNA.
+__global__ void __launch_bounds__(64) k_argmax_recovery(const float* __restrict__ logits, const float* __restrict__ mask,
+        const int32_t* __restrict__ labels, int T, int8_t* __restrict__ pred, int32_t* __restrict__ correct,
+        int32_t* __restrict__ valid) {
+    int b = blockIdx.x;
+    int ok = 0, nv = 0;
+    for (int t = threadIdx.x; t < T; t += 64) {
+        size_t i = (size_t)b * T + t;
+        if (mask[i] != 0.f) {
+            const float4 v = *reinterpret_cast<const float4*>(logits + i * 4);
+            int a = 0; float best = v.x;
+            if (v.y > best) { best = v.y; a = 1; }
+            if (v.z > best) { best = v.z; a = 2; }
+            if (v.w > best) { best = v.w; a = 3; }
+            if (pred) pred[i] = (int8_t)a;
+            nv += 1;
+            if (labels) ok += (labels[i] == a);
+        } else if (pred) pred[i] = -1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ok += __shfl_xor(ok, o, 64); nv += __shfl_xor(nv, o, 64); }
+    if (threadIdx.x == 0) { if (correct) correct[b] = ok; if (valid) valid[b] = nv; }
+}
+void launch_argmax_recovery(const float* logits, const float* mask, const int32_t* labels, int B, int T,
+                            int8_t* pred, int32_t* correct, int32_t* valid, hipStream_t s) {
+    hipLaunchKernelGGL(k_argmax_recovery, dim3(B), dim3(64), 0, s, logits, mask, labels, T, pred, correct, valid);
+}
+
+// sample(): independent categorical draw per position from softmax(logits / temperature).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+__global__ void k_sample(const float* __restrict__ logits, const float* __restrict__ mask, int B, int T, float inv_temp,
+                         int n_samples, unsigned long long seed, int8_t* __restrict__ out) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per = (size_t)B * T;
+    if (id >= per * n_samples) return;
+    size_t i = id % per;
+    if (mask[i] == 0.f) { out[id] = -1; return; }
+    const float4 v = *reinterpret_cast<const float4*>(logits + i * 4);
+    float z0 = v.x * inv_temp, z1 = v.y * inv_temp, z2 = v.z * inv_temp, z3 = v.w * inv_temp;
+    float mx = fmaxf(fmaxf(z0, z1), fmaxf(z2, z3));
+    float p0 = expf(z0 - mx), p1 = expf(z1 - mx), p2 = expf(z2 - mx), p3 = expf(z3 - mx);
+    float tot = p0 + p1 + p2 + p3;
+    unsigned long long bits = mix64(mix64((id + 1) * 0x9E3779B97F4A7C15ull + seed) ^ (seed * 0xD6E8FEB86659FD93ull));
+    float u = (float)(bits >> 40) * (1.0f / 16777216.0f) * tot;     // uniform in [0, tot)
+    int a = 3;
+    if (u < p0) a = 0; else if (u < p0 + p1) a = 1; else if (u < p0 + p1 + p2) a = 2;
+    out[id] = (int8_t)a;
+}
+void launch_sample(const float* logits, const float* mask, int B, int T, float temperature, int n_samples,
+                   uint64_t seed, int8_t* out, hipStream_t s) {
+    size_t total = (size_t)B * T * n_samples;
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits, mask, B, T,
+                       1.0f / temperature, n_samples, (unsigned long long)seed, out);
+}

@@ -1,0 +1,137 @@
+"""Shared host-side plumbing of the drop-in modules: parameter containers with the reference's
+state-dict keys, weight upload into the HIP library, workspace and stream handling.
+PyTorch is used for device memory, streams and parameters only; all arithmetic of the path
+runs in ``librnampnn_hip.so``."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .. import _native
+from ._schema import DEFAULT_HPARAMS, state_dict_shapes
+
+DEFAULT_PRECISION = os.environ.get("RNAMPNN_PRECISION", "bf16")
+_PREC = {"f32": _native.PREC_F32, "fp32": _native.PREC_F32, "float32": _native.PREC_F32,
+         "bf16": _native.PREC_BF16, "bfloat16": _native.PREC_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _prep(t: torch.Tensor, device, dtype=torch.float32) -> torch.Tensor:
+    """Caller tensors are const inputs: cast/move/contiguous-ify into a private copy if needed."""
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+def _register_nested(root: nn.Module, key: str, param: nn.Parameter) -> None:
+    parts = key.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, nn.Module())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], param)
+
+
+def _init_like_reference(key: str, shape) -> torch.Tensor:
+    """torch's default initialisers of the reference's layers (nn.Linear, nn.MultiheadAttention,
+    GraphNormalization ones/zeros)."""
+    leaf = key.rsplit(".", 1)[-1]
+    t = torch.empty(shape, dtype=torch.float32)
+    if leaf == "scale":
+        return t.fill_(1.0)
+    if leaf == "shift":
+        return t.zero_()
+    if leaf == "in_proj_weight":
+        return nn.init.xavier_uniform_(t)
+    if leaf == "in_proj_bias" or key.endswith("out_proj.bias"):
+        return t.zero_()
+    if leaf == "weight":
+        return nn.init.kaiming_uniform_(t, a=5 ** 0.5)
+    fan_in = None
+    return t.uniform_(-1, 1)  # bias: scaled by the caller (needs the sibling's fan-in)
+
+
+class NativeModule(nn.Module):
+    """Base of every drop-in class.  ``hp`` are the full RNAMPNN hyper-parameters the C handle
+    is created with; ``prefix`` selects which state-dict entries this module owns (the others,
+    needed only to make the handle complete, are zero-filled at upload)."""
+
+    def _setup(self, hp: Dict, prefix: str, precision: Optional[str]) -> None:
+        full = OrderedDict(DEFAULT_HPARAMS)
+        full.update(hp)
+        self._hp = full
+        self._prefix = prefix
+        prec = (precision or DEFAULT_PRECISION).lower()
+        if prec not in _PREC:
+            raise ValueError(f"precision must be one of {sorted(_PREC)}, got {precision!r}")
+        self.precision = "bf16" if _PREC[prec] == _native.PREC_BF16 else "f32"
+        self._shapes = state_dict_shapes(full)
+        for key, shape in self._shapes.items():
+            if not key.startswith(prefix):
+                continue
+            t = _init_like_reference(key, shape)
+            if key.endswith("bias") and not key.endswith("in_proj_bias") and not key.endswith("out_proj.bias"):
+                fan_in = self._shapes[key[:-4] + "weight"][-1]
+                t.mul_(1.0 / fan_in ** 0.5)
+            _register_nested(self, key[len(prefix):], nn.Parameter(t))
+        self._handle: Optional[_native.Handle] = None
+        self._synced = None
+        self._ws: Optional[torch.Tensor] = None
+        self._warned_train = False
+
+    # ------------------------------------------------------------------ native state
+    def _device(self) -> torch.device:
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError("the RNA-MPNN HIP path runs on an MI355X: move the module to 'cuda' first "
+                               "(there is no CPU fallback)")
+        return p.device
+
+    def _ensure(self) -> torch.device:
+        device = self._device()
+        if self.training and not self._warned_train:
+            self._warned_train = True
+            import warnings
+            warnings.warn("rnampnn HIP forward implements eval-mode semantics (dropout inactive)")
+        if self._handle is None:
+            self._handle = _native.Handle(self._hp, _PREC[self.precision])
+        named = dict(self.named_parameters())
+        sig = tuple((k, p.data_ptr(), p._version) for k, p in named.items())
+        if sig != self._synced:
+            lib = _native.lib()
+            st = _stream(device)
+            with torch.cuda.device(device):
+                for key, shape in self._shapes.items():
+                    if key.startswith(self._prefix):
+                        src = _prep(named[key[len(self._prefix):]].data, device)
+                    else:
+                        src = torch.zeros(shape, dtype=torch.float32, device=device)
+                    _native.check(lib.rnampnn_set_weight(self._handle.ptr, key.encode(), _ptr(src), src.numel(), 0, st))
+                    src.record_stream(torch.cuda.current_stream(device))
+                _native.check(lib.rnampnn_finalize_weights(self._handle.ptr, st))
+            self._synced = sig
+        return device
+
+    def _workspace(self, B: int, T: int, device) -> torch.Tensor:
+        need = int(_native.lib().rnampnn_workspace_bytes(self._handle.ptr, B, T))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _ws_args(self, B: int, T: int, device):
+        ws = self._workspace(B, T, device)
+        base = ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        return C.c_void_p(aligned), C.c_size_t(ws.numel() - (aligned - base))

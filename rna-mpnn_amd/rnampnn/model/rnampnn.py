@@ -1,0 +1,173 @@
+"""Drop-in for the reference's ``rnampnn/model/rnampnn.py``: ``RNAMPNN`` with the same constructor
+hyper-parameters (``rnampnn.py:19-54``), ``forward`` / ``embedding`` signatures (``:161-185,269-278``),
+state-dict keys, loss (``:151-154``), optimiser (``:156-159``) and validation metrics (``:209-236``),
+running on hand-written HIP kernels through the C ABI of ``include/rnampnn_hip.h``.
+
+Not mirrored: the Lightning base class, the XGBoost read-out (third-party, not installed, no
+pickle ships; ``predict`` uses the ``Readout`` argmax as ``rdesign/model/rdesign.py:152-155`` does)
+and checkpoint hooks.  New (no reference counterpart): ``sample()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .. import _native
+from ..config.glob import REVERSE_VOCAB
+from ._base import NativeModule, _prep, _ptr, _stream
+from ._schema import DEFAULT_HPARAMS
+
+_FIXED_ATOMS = dict(num_inside_dist_atoms=7, num_inside_angle_atoms=6, num_inside_dihedral_atoms=6,
+                    num_cross_dist_atoms=7, num_cross_angle_atoms=6, num_cross_dihedral_atoms=6)
+
+
+class RNAMPNN(NativeModule):
+    def __init__(self, precision: Optional[str] = None, **hparams):
+        super().__init__()
+        unknown = set(hparams) - set(DEFAULT_HPARAMS)
+        if unknown:
+            raise TypeError(f"RNAMPNN.__init__() got unexpected keyword arguments {sorted(unknown)}")
+        for k, v in _FIXED_ATOMS.items():
+            if hparams.get(k, v) != v:
+                raise NotImplementedError(f"{k}={hparams[k]}: the HIP featurisation kernels are built for the "
+                                          f"reference default {v} (28 node / 90 edge raw features)")
+        self.name = 'RNAMPNN-X'
+        self.version = 0
+        self._setup(hparams, "", precision)
+        self.hparams = dict(self._hp)
+        self.val_step_outputs = {'val_loss': [], 'correct': [], 'len': [], 'recovery_rates': []}
+
+    # ------------------------------------------------------------------ forward surface
+    def _run(self, coords, mask, want_logits=True, want_embedding=False, T_norm: int = 0, taps: Optional[Dict] = None):
+        device = self._ensure()
+        if coords.dim() != 4 or coords.shape[2:] != (7, 3):
+            raise ValueError(f"coords must be (B, T, 7, 3), got {tuple(coords.shape)}")
+        B, T = int(coords.shape[0]), int(coords.shape[1])
+        if tuple(mask.shape) != (B, T):
+            raise ValueError(f"mask must be (B, T) = {(B, T)}, got {tuple(mask.shape)}")
+        c = _prep(coords, device)
+        m = _prep(mask, device)
+        k = self._hp["num_res_neighbours"]
+        io = _native.RnaMpnnForwardIO()
+        io.coords, io.mask, io.B, io.T, io.T_norm, io.stop_after = _ptr(c), _ptr(m), B, T, int(T_norm), 0
+        out = {}
+        if want_logits:
+            out["logits"] = torch.empty(B, T, 4, dtype=torch.float32, device=device)
+            io.logits = _ptr(out["logits"])
+        if want_embedding:
+            out["embedding"] = torch.empty(B, T, 256, dtype=torch.float32, device=device)
+            io.embedding = _ptr(out["embedding"])
+        if taps:
+            shapes = {"edge_index": ((B, T, k), torch.int64), "raw": ((B, T, 28), torch.float32),
+                      "h0": ((B, T, 128), torch.float32), "e0": ((B, T, k, 128), torch.float32),
+                      "h_layer": ((B, T, 128), torch.float32), "e_layer": ((B, T, k, 128), torch.float32),
+                      "h_post": ((B, T, 128), torch.float32), "raw_emb": ((B, T, 128), torch.float32)}
+            for name in taps.get("names", ()):
+                shp, dt = shapes[name]
+                out[name] = torch.empty(shp, dtype=dt, device=device)
+                setattr(io, name, _ptr(out[name]))
+            io.tap_layer = int(taps.get("tap_layer", 0))
+            io.stop_after = int(taps.get("stop_after", 0))
+        with torch.cuda.device(device):
+            ws, ws_bytes = self._ws_args(B, T, device)
+            _native.check(_native.lib().rnampnn_forward(self._handle.ptr, C.byref(io), ws, ws_bytes, _stream(device)))
+        return out
+
+    def forward(self, coords: torch.Tensor, mask: torch.Tensor, is_predict: bool = False, T_norm: int = 0) -> torch.Tensor:
+        """``RNAMPNN.forward`` (rnampnn.py:161-185): logits (B, T, 4), zero on padded rows.
+        ``T_norm`` (extension): node-axis length GraphNormalization should see when this call holds
+        only a shard of a padded global batch (0 = this tensor's T)."""
+        return self._run(coords, mask, T_norm=T_norm)["logits"]
+
+    def embedding(self, coords: torch.Tensor, mask: torch.Tensor, is_predict: bool = False, T_norm: int = 0) -> torch.Tensor:
+        """``RNAMPNN.embedding`` (rnampnn.py:269-278): cat(post-fusion h, raw embedding), (B, T, 256)."""
+        return self._run(coords, mask, want_logits=False, want_embedding=True, T_norm=T_norm)["embedding"]
+
+    def forward_taps(self, coords, mask, names, tap_layer: int = 0, T_norm: int = 0):
+        """Forward with intermediate tensors (parity tests): ``names`` from edge_index, raw, h0, e0,
+        h_layer, e_layer, h_post, raw_emb; ``tap_layer`` is the 1-based ResMPNN layer of h_/e_layer."""
+        return self._run(coords, mask, want_logits=True, want_embedding=True, T_norm=T_norm,
+                         taps=dict(names=tuple(names), tap_layer=tap_layer))
+
+    # ------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def sample(self, coords: torch.Tensor, mask: torch.Tensor, temperature: float = 0.1, n_samples: int = 8,
+               seed: int = 0, T_norm: int = 0) -> torch.Tensor:
+        """Draw ``n_samples`` sequences per structure, independently per position, from
+        softmax(logits / temperature) -> int8 (n_samples, B, T), -1 on padding.  The reference has no
+        sampler (its decode is one-shot argmax); temperature -> 0 reproduces that argmax."""
+        logits = self.forward(coords, mask, T_norm=T_norm)
+        return sample_from_logits(logits, mask, temperature, n_samples, seed)
+
+    @torch.no_grad()
+    def predict_sequences(self, coords: torch.Tensor, mask: torch.Tensor) -> List[str]:
+        """Readout-argmax decode to strings (what ``predict`` writes, rnampnn.py:300-305, with the
+        Readout standing in for the missing XGBoost classifier)."""
+        logits = self.forward(coords, mask)
+        pred, _, _ = argmax_recovery(logits, mask, None)
+        pred = pred.cpu()
+        return ["".join(REVERSE_VOCAB[int(i)] for i in row[row >= 0]) for row in pred]
+
+    # ------------------------------------------------------------------ training / validation surface
+    @staticmethod
+    def mix_loss(valid_probs, valid_sequences):
+        # rnampnn.py:151-154 - cross_entropy applied to PROBABILITIES (softmax twice), a reference quirk
+        return F.cross_entropy(valid_probs, valid_sequences.argmax(dim=-1), reduction='mean')
+
+    def configure_optimizers(self):
+        # rnampnn.py:156-159
+        optimizer = torch.optim.Adam(self.parameters(), lr=self._hp["lr"], weight_decay=self._hp["weight_decay"])
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=15, gamma=0.8)
+        return [optimizer], [scheduler]
+
+    @torch.no_grad()
+    def validation_step(self, batch):
+        """rnampnn.py:209-236: loss + per-RNA recovery; the argmax / per-RNA reduction that the
+        reference does on the CPU (``separate``, utils/data.py:594-604) runs in one HIP kernel."""
+        sequences, coords, mask, _ = batch
+        device = self._device()
+        sequences, mask = sequences.to(device), mask.to(device)
+        logits = self.forward(coords, mask)
+        probs = F.softmax(logits, dim=-1)
+        valid = mask.bool()
+        loss = self.mix_loss(probs[valid], sequences[valid])
+        _, correct, nvalid = argmax_recovery(logits, mask, sequences.argmax(dim=-1))
+        recovery_rates = (correct.float() / nvalid.float().clamp(min=1)).tolist()
+        n_tot = int(nvalid.sum())
+        self.val_step_outputs['val_loss'].append(loss * n_tot)
+        self.val_step_outputs['correct'].append(int(correct.sum()))
+        self.val_step_outputs['len'].append(n_tot)
+        self.val_step_outputs['recovery_rates'] += recovery_rates
+        return {'validation loss': loss, 'recovery_rates': recovery_rates}
+
+
+def argmax_recovery(logits: torch.Tensor, mask: torch.Tensor, labels: Optional[torch.Tensor]
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """HIP decode kernel: (pred int8 (B,T) with -1 on padding, correct int32 (B,), valid int32 (B,))."""
+    device = logits.device
+    B, T = int(logits.shape[0]), int(logits.shape[1])
+    lg, m = _prep(logits, device), _prep(mask, device)
+    lab = None if labels is None else _prep(labels, device, torch.int32)
+    pred = torch.empty(B, T, dtype=torch.int8, device=device)
+    correct = torch.zeros(B, dtype=torch.int32, device=device)
+    nvalid = torch.zeros(B, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _native.check(_native.lib().rnampnn_argmax_recovery(_ptr(lg), _ptr(m), _ptr(lab), B, T, _ptr(pred),
+                                                            _ptr(correct), _ptr(nvalid), _stream(device)))
+    return pred, correct, nvalid
+
+
+def sample_from_logits(logits: torch.Tensor, mask: torch.Tensor, temperature: float, n_samples: int, seed: int = 0
+                       ) -> torch.Tensor:
+    device = logits.device
+    B, T = int(logits.shape[0]), int(logits.shape[1])
+    lg, m = _prep(logits, device), _prep(mask, device)
+    out = torch.empty(n_samples, B, T, dtype=torch.int8, device=device)
+    with torch.cuda.device(device):
+        _native.check(_native.lib().rnampnn_sample(_ptr(lg), _ptr(m), B, T, float(temperature), int(n_samples),
+                                                   C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(out), _stream(device)))
+    return out

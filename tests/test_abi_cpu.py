@@ -1,0 +1,90 @@
+"""CPU checks of the boundary: the C-ABI library loads, exports every symbol that
+include/rnampnn_hip.h declares, and registers exactly the reference's state-dict schema.
+No compute is launched (there is no GPU in the build container)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, REPO
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from rnampnn import _native
+    return _native
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "rnampnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rnampnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = native.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rnampnn_hip.h but not exported"
+    assert sorted(native.SYMBOLS) == declared
+    assert b"gfx950" in lib.rnampnn_version()
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_schema_matches_reference_state_dict(native, golden, name):
+    """Keys, order and shapes equal the reference model's state_dict recorded in the fixture."""
+    from rnampnn.model._schema import state_dict_shapes, DEFAULT_HPARAMS
+    arrs, hp, shapes = golden(name)
+    full = dict(DEFAULT_HPARAMS); full.update(hp)
+    mine = state_dict_shapes(full)
+    assert list(mine.keys()) == list(shapes.keys())
+    assert all(tuple(mine[k]) == tuple(shapes[k]) for k in mine)
+    h = native.Handle(full, native.PREC_F32)
+    sch = h.weight_schema()
+    assert [k for k, _ in sch] == list(shapes.keys())
+    assert all(n == int(np.prod(shapes[k])) for k, n in sch)
+    h.close()
+
+
+def test_default_model_has_reference_parameter_count():
+    from rnampnn.model.rnampnn import RNAMPNN
+    m = RNAMPNN(precision="f32")
+    assert sum(p.numel() for p in m.parameters()) == 3_536_900
+
+
+def test_error_codes_map_to_reference_exceptions(native):
+    from rnampnn.model._schema import DEFAULT_HPARAMS
+    hp = dict(DEFAULT_HPARAMS)
+    with pytest.raises(NotImplementedError):
+        native.Handle(dict(hp, num_res_neighbours=64), native.PREC_F32)     # k > KMAX
+    with pytest.raises(NotImplementedError):
+        native.Handle(dict(hp, res_embedding_dim=64), native.PREC_F32)
+    with pytest.raises(ValueError):
+        native.Handle(dict(hp, num_res_neighbours=0), native.PREC_F32)
+    from rnampnn.model.feature import ResFeature
+    with pytest.raises(AssertionError):
+        ResFeature(num_neighbours=3, num_inside_dist_atoms=1)               # feature.py:169
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a GPU instead of computing elsewhere."""
+    import torch
+    from rnampnn.model.rnampnn import RNAMPNN
+    m = RNAMPNN(precision="f32", num_res_mpnn_layers=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 7, 3), torch.ones(1, 4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "rna-mpnn_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "rnampnn_oracle" not in text, f

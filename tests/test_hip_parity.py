@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in Python classes) against
+(a) the committed golden vectors of the reference's own modules and (b) the CPU oracle on
+seeded synthetic inputs.
+
+Tolerances: f32 kernels |dlogit| <= 1e-4 and identical argmax except
+near-ties; bf16 kernels |dlogit| <= 5e-2 and recovery within +-0.5 pt of the f32 path.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FULL_CASES, GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+F32_LOGIT_TOL = 1e-4
+BF16_LOGIT_TOL = 5e-2
+
+
+def _model(hp, shapes, precision):
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.model._schema import DEFAULT_HPARAMS
+    from rnampnn.utils import synth
+    kw = {k: v for k, v in hp.items() if k in DEFAULT_HPARAMS}
+    model = RNAMPNN(precision=precision, **kw)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == shapes
+    sd = synth.closed_form_state_dict(shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.to("cuda:0").eval(), sd
+
+
+def _oracle(hp, sd, coords, mask, taps=None):
+    from oracle import rnampnn_oracle as O
+    cfg = O.OracleConfig(**{k: v for k, v in hp.items() if k in O.OracleConfig.__dataclass_fields__})
+    return O.forward(torch.from_numpy(coords), torch.from_numpy(mask), O.state_dict_from_numpy(sd), cfg, taps=taps)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_f32_logits_match_reference_golden(golden, name):
+    arrs, hp, shapes = golden(name)
+    model, _ = _model(hp, shapes, "f32")
+    coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
+    out = model.forward_taps(coords, mask, ["edge_index"])
+    logits = out["logits"].cpu().numpy()
+    assert np.isfinite(logits).all()
+    err = np.abs(logits - arrs["logits"]).max()
+    assert err < F32_LOGIT_TOL, f"{name}: |dlogit| = {err:.3e}"
+    # padded rows are exactly zero (functional.py:88)
+    assert (logits[arrs["mask"] == 0] == 0).all()
+    # k-NN graph bit-exact up to the documented phantom-index equivalence class
+    from oracle import rnampnn_oracle as O
+    ref_idx = O.canonical_edge_index(torch.from_numpy(arrs["edge_index"]).long(), mask)
+    assert torch.equal(out["edge_index"].cpu(), ref_idx), name
+    # argmax agreement outside near-ties
+    top2 = np.sort(arrs["logits"], -1)
+    clear = (top2[..., -1] - top2[..., -2]) > 5e-4
+    assert (logits.argmax(-1) == arrs["logits"].argmax(-1))[clear].all()
+
+
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_f32_stage_taps_match_reference_golden(golden, name):
+    arrs, hp, shapes = golden(name)
+    model, _ = _model(hp, shapes, "f32")
+    coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
+    out = model.forward_taps(coords, mask, ["edge_index", "raw", "h0", "e0", "h_layer", "e_layer", "h_post", "raw_emb"],
+                             tap_layer=1)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.allclose(out["raw"], arrs["raw"], rtol=1e-5, atol=1e-5)
+    for key, ref_key in (("h0", "h0"), ("h_layer", "h1"), ("h_post", "h_post"), ("raw_emb", "raw_emb")):
+        err = np.abs(out[key] - arrs[ref_key]).max()
+        assert err < 2e-4, f"{name}: {key} differs by {err:.3e}"
+    emb = np.concatenate([arrs["h_post"], arrs["raw_emb"]], -1)
+    assert np.abs(out["embedding"] - emb).max() < 2e-4
+    en = arrs["e0"].shape[1]
+    valid = (out["edge_index"][:, :en] != -1)[..., None]
+    assert np.abs((out["e0"][:, :en] - arrs["e0"]) * valid).max() < 2e-4
+    assert np.abs((out["e_layer"][:, :en] - arrs["e1"]) * valid).max() < 2e-4
+    # documented difference: invalid slots of e are zero (the reference leaves unconsumed garbage)
+    assert (out["e_layer"][:, :en][~np.broadcast_to(valid, out["e_layer"][:, :en].shape)] == 0).all()
+
+
+def test_f32_matches_oracle_on_synthetic_batch():
+    """Seeded synthetic ragged batch, k=30, vs the CPU oracle incl. recovery and the quirk loss."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    from rnampnn.model.rnampnn import argmax_recovery
+    from oracle import rnampnn_oracle as O
+    lens = [61, 30, 12, 75, 2, 44]
+    coords, mask, labels = synth.synth_batch(lens, first_index=300)
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=30, padding_len=96, num_res_mpnn_layers=4)
+    model, sd = _model(hp, state_dict_shapes(hp), "f32")
+    logits = model(torch.from_numpy(coords), torch.from_numpy(mask))
+    ref, ref_emb = _oracle(hp, sd, coords, mask)
+    assert (logits.cpu() - ref).abs().max() < F32_LOGIT_TOL
+    emb = model.embedding(torch.from_numpy(coords), torch.from_numpy(mask)).cpu()
+    assert (emb - ref_emb).abs().max() < 2e-4
+    pred, correct, nvalid = argmax_recovery(logits, torch.from_numpy(mask).cuda(), torch.from_numpy(labels).cuda())
+    micro, macro, per = O.recovery(ref, torch.from_numpy(mask), torch.from_numpy(labels))
+    assert nvalid.cpu().tolist() == lens
+    mine_micro = float(correct.sum()) / float(nvalid.sum())
+    assert abs(mine_micro - micro) < 1e-9 or (logits.cpu() - ref).abs().max() > 0   # ties aside, identical
+    assert np.allclose((correct.float() / nvalid.float()).cpu().numpy(), per.numpy(), atol=1e-6)
+    loss = O.loss_double_softmax(logits.cpu(), torch.from_numpy(mask), torch.from_numpy(labels))
+    ref_loss = O.loss_double_softmax(ref, torch.from_numpy(mask), torch.from_numpy(labels))
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+
+
+def test_T_norm_reproduces_global_batch_padding():
+    """A shard that passes the global max_len as T_norm reproduces the padded-batch result
+    (padding-dependent GraphNorm)."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    lens = [50, 20, 35, 41]
+    coords, mask, _ = synth.synth_batch(lens, first_index=10)
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=16, padding_len=64, num_res_mpnn_layers=3)
+    model, _ = _model(hp, state_dict_shapes(hp), "f32")
+    full = model(torch.from_numpy(coords), torch.from_numpy(mask)).cpu()
+    # shard = RNAs 1 and 2 only, tensors cut to the shard's own max_len 35, T_norm = global 50
+    c3, m3 = coords[1:3, :36], mask[1:3, :36]
+    part = model(torch.from_numpy(c3), torch.from_numpy(m3), T_norm=50).cpu()
+    assert (part[:, :35] - full[1:3, :35]).abs().max() < 2e-5
+    own = model(torch.from_numpy(c3), torch.from_numpy(m3)).cpu()
+    assert (own[:, :35] - full[1:3, :35]).abs().max() > 1e-4       # without T_norm the result differs
+
+
+def test_standalone_stage_modules_match_oracle():
+    """ResFeature / ResMPNN / RNABert / RawFFN / Readout / GraphNormalization as the reference's
+    stand-alone classes (test.py:74-81 call shapes)."""
+    from oracle import rnampnn_oracle as O
+    from rnampnn.model.feature import ResFeature
+    from rnampnn.model.mpnn import ResMPNN
+    from rnampnn.model.functional import GraphNormalization, RNABert, RawFFN, Readout
+    from rnampnn.utils import synth
+    lens = [23, 40, 9]
+    coords, mask, _ = synth.synth_batch(lens, first_index=50)
+    ct, mt = torch.from_numpy(coords), torch.from_numpy(mask)
+
+    def load(mod):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        sd = synth.closed_form_state_dict(shapes)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return mod.to("cuda:0").eval(), {k: torch.from_numpy(v) for k, v in sd.items()}
+
+    k = 7
+    feat, sdf = load(ResFeature(num_neighbours=k, padding_len=64, num_attn_layers=1, num_heads=4, ffn_dim=128,
+                                num_ffn_layers=2, precision="f32"))
+    raw, h, e, idx = feat(ct, mt)
+    cfg = O.OracleConfig(num_res_neighbours=k, padding_len=64, num_embedding_attn_layers=1, num_embedding_heads=4,
+                         embedding_ffn_dim=128, num_embedding_ffn_layers=2)
+    o_raw, o_h, o_e, o_idx = O.res_feature(ct, mt, {"res_feature." + kk: v for kk, v in sdf.items()}, cfg)
+    assert torch.equal(idx.cpu(), o_idx)
+    assert (h.cpu() - o_h).abs().max() < 2e-4 and (e.cpu() - o_e).abs().max() < 2e-4
+    assert torch.allclose(raw.cpu(), o_raw, rtol=1e-5, atol=1e-5)
+
+    layer, sdl = load(ResMPNN(128, 128, 2, 2, 0.4, precision="f32"))
+    sd_full = {"res_mpnn_layers.0." + kk: v for kk, v in sdl.items()}
+    msg = layer.message(h, e, idx, mt)
+    o_msg = O.mpnn_message(o_h, o_e, o_idx, mt, sd_full, "res_mpnn_layers.0", 2)
+    assert (msg.cpu() - o_msg).abs().max() < 2e-4
+    h1, e1 = layer(h, e, idx, mt)
+    o_h1, o_e1 = O.mpnn_layer(o_h, o_e, o_idx, mt, sd_full, 0, cfg)
+    valid = (o_idx != -1).unsqueeze(-1)
+    assert (h1.cpu() - o_h1).abs().max() < 2e-4
+    assert ((e1.cpu() - o_e1) * valid).abs().max() < 2e-4
+    assert torch.equal(e.cpu(), o_e) or (e.cpu() - o_e).abs().max() < 2e-4     # caller's e is not mutated
+
+    bert, sdb = load(RNABert(padding_len=100, res_embedding_dim=128, num_attn_layers=2, num_heads=8, ffn_dim=256,
+                             num_ffn_layers=2, precision="f32"))
+    y = bert(h1, mt)
+    o_y = O.rnabert(o_h1, mt, {"post_fusion." + kk: v for kk, v in sdb.items()}, "post_fusion", 2, 8, 2, 100)
+    assert (y.cpu() - o_y).abs().max() < 2e-4
+
+    rf, sdr = load(RawFFN(28, 256, 2, 128, precision="f32"))
+    z = rf(raw, mt)
+    o_z = O.raw_ffn(o_raw, mt, {"raw_embedding." + kk: v for kk, v in sdr.items()}, O.OracleConfig(num_raw_ffn_layers=2))
+    assert (z.cpu() - o_z).abs().max() < 2e-4
+
+    ro, sdo = load(Readout(256, 384, 2, precision="f32"))
+    emb = torch.cat([y, z], -1)
+    lg = ro(emb, mt)
+    o_lg = O.readout(torch.cat([o_y, o_z], -1), mt, {"readout." + kk: v for kk, v in sdo.items()},
+                     O.OracleConfig(num_readout_layers=2))
+    assert (lg.cpu() - o_lg).abs().max() < 1e-4
+
+    gn = GraphNormalization(128).to("cuda:0")
+    with torch.no_grad():
+        gn.scale.copy_(torch.rand(1, 1, 128) + 0.5)
+        gn.shift.copy_(torch.rand(1, 1, 128))
+    x = torch.randn(3, 40, 128)
+    g = gn(x, mt)
+    o_g = O.graph_norm(x, mt, gn.scale.cpu().detach(), gn.shift.cpu().detach())
+    assert (g.cpu() - o_g).abs().max() < 1e-5
+    g2 = gn(x, mt, t_tot=64)
+    o_g2 = O._graph_norm_ttot(x, mt, gn.scale.cpu().detach().view(-1), gn.shift.cpu().detach().view(-1), 64)
+    assert (g2.cpu() - o_g2).abs().max() < 1e-5
+
+
+def test_error_behaviour_matches_reference():
+    from rnampnn.model.rnampnn import RNAMPNN
+    m = RNAMPNN(precision="f32", num_res_mpnn_layers=1, padding_len=16).to("cuda:0").eval()
+    with pytest.raises(RuntimeError):          # max_len > padding_len (functional.py:155)
+        m(torch.zeros(1, 20, 7, 3), torch.ones(1, 20))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 8, 6, 3), torch.ones(1, 8))
+
+
+def test_sample_and_argmax_decode():
+    """sample(): -1 on padding; temperature -> 0 equals the (pinned) argmax; at T=1 the empirical
+    distribution follows softmax(logits) (chi-square style bound)."""
+    from rnampnn.model.rnampnn import argmax_recovery, sample_from_logits
+    torch.manual_seed(0)
+    B, T = 4, 50
+    logits = torch.randn(B, T, 4, device="cuda")
+    mask = torch.ones(B, T, device="cuda")
+    mask[1, 30:] = 0
+    pred, _, nvalid = argmax_recovery(logits, mask, None)
+    assert nvalid.tolist() == [50, 30, 50, 50]
+    assert torch.equal(pred[mask.bool()].long(), logits.argmax(-1)[mask.bool()])
+    assert (pred[~mask.bool()] == -1).all()
+    cold = sample_from_logits(logits, mask, 1e-4, 3, seed=1)
+    assert (cold == pred.unsqueeze(0)).all()
+    n = 4000
+    hot = sample_from_logits(logits, mask, 1.0, n, seed=2)
+    assert (hot[:, ~mask.bool()] == -1).all()
+    probs = torch.softmax(logits, -1)
+    freq = torch.stack([(hot == c).float().mean(0) for c in range(4)], -1)
+    assert ((freq - probs).abs()[mask.bool()]).max() < 0.05
+    again = sample_from_logits(logits, mask, 1.0, 8, seed=2)
+    assert torch.equal(again, hot[:8])          # counter-based RNG: reproducible
+
+
+@pytest.mark.parametrize("name", ["c1_1b23_k16_P66", "ragged_k30", "c2_mini_k30", "c1_1b23_k30_T80"])
+def test_bf16_path_within_tolerance(golden, name):
+    arrs, hp, shapes = golden(name)
+    coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
+    try:
+        model, _ = _model(hp, shapes, "bf16")
+        logits = model(coords, mask).cpu().numpy()
+    except NotImplementedError as exc:
+        pytest.skip(f"bf16 kernels unavailable for this configuration: {exc}")
+    assert np.isfinite(logits).all()
+    err = np.abs(logits - arrs["logits"]).max()
+    assert err < BF16_LOGIT_TOL, f"{name}: |dlogit| = {err:.3e}"
+    labels = arrs["labels"]
+    valid = arrs["mask"] > 0
+    rec_bf16 = (logits.argmax(-1) == labels)[valid].mean()
+    rec_f32 = (arrs["logits"].argmax(-1) == labels)[valid].mean()
+    print(f"{name}: bf16 |dlogit|max {err:.3e}, recovery bf16 {rec_bf16:.4f} vs f32 {rec_f32:.4f}")
