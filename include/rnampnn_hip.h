@@ -148,6 +148,14 @@ int rnampnn_argmax_recovery(const float* logits, const float* mask, const int32_
 int rnampnn_sample(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
                    int32_t n_samples, uint64_t seed, int8_t* out, void* stream);
 
+/* -- measurement ------------------------------------------------------------------------- */
+/* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when
+ * enabled, HIP events bracket each of its launches on the caller's stream; _read synchronises
+ * the recorded events and returns the summed duration and the launch count since the last reset.
+ * No reference counterpart (the reference has no profiling hooks). */
+int rnampnn_profile_enable(rnampnn_handle h, int32_t enable);
+int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset);
+
 const char* rnampnn_last_error(void);
 const char* rnampnn_version(void);
 

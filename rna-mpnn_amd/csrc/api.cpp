@@ -76,6 +76,12 @@ struct rnampnn_ctx {
     int rawffn_gn_scale, rawffn_gn_shift;
     std::vector<Lin> readout;
     int fmax = 0;                 // widest node activation
+    // optional live timing of the dominant kernel (bench.py roofline leg)
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    long long prof_n = 0;
 };
 
 static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {
@@ -227,8 +233,35 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
     return RNAMPNN_OK;
 }
 
+extern "C" int rnampnn_profile_enable(rnampnn_handle h, int32_t enable) {
+    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+    if (enable && h->ev.empty()) {
+        h->ev.resize(2 * 8192);
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    h->prof = enable != 0;
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset) {
+    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->prof_ms += ms;
+        h->prof_n += 1;
+    }
+    h->ev_used = 0;
+    if (kernel_ms) *kernel_ms = h->prof_ms;
+    if (launches) *launches = h->prof_n;
+    if (reset) { h->prof_ms = 0.0; h->prof_n = 0; }
+    return RNAMPNN_OK;
+}
+
 extern "C" int rnampnn_destroy(rnampnn_handle h) {
     if (!h) return RNAMPNN_OK;
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->raw_arena) (void)hipFree(h->raw_arena);
     if (h->der_arena) (void)hipFree(h->der_arena);
     delete h;
@@ -445,6 +478,8 @@ static MpnnWB wbf(rnampnn_ctx* c, const Mlp2& m) {
 static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in, float* h_pre, float* msg_out) {
     rnampnn_ctx* c = r.c;
     int k = c->cfg.num_res_neighbours;
+    bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
+    if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
     if (r.fast) {
         launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.pq_m,
                          we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_in, h_pre, msg_out, r.s);
@@ -453,6 +488,7 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
         launch_mpnn_f32(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (float*)r.w.e, r.w.pq_e, r.w.pq_m, e32, m32,
                         h_in, h_pre, msg_out, r.s);
     }
+    if (timed) { (void)hipEventRecord(c->ev[c->ev_used + 1], r.s); c->ev_used += 2; }
 }
 
 static void unpack_e(Run& r, float* dst) {

@@ -135,3 +135,15 @@ class NativeModule(nn.Module):
         base = ws.data_ptr()
         aligned = (base + 255) // 256 * 256
         return C.c_void_p(aligned), C.c_size_t(ws.numel() - (aligned - base))
+
+    # ------------------------------------------------------------------ measurement hooks
+    def profile_enable(self, enable: bool = True) -> None:
+        """HIP-event timing of every launch of the dominant (fused ResMPNN edge) kernel."""
+        self._ensure()
+        _native.check(_native.lib().rnampnn_profile_enable(self._handle.ptr, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True):
+        """-> (summed kernel milliseconds, launches) since the last reset (synchronises the events)."""
+        ms, n = C.c_double(), C.c_int64()
+        _native.check(_native.lib().rnampnn_profile_read(self._handle.ptr, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return float(ms.value), int(n.value)
