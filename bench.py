@@ -193,7 +193,13 @@ def cpu_baseline(args, hp, sd, coords, mask, labels, lens, gpu_logits, out):
     full = dict(DEFAULT_HPARAMS, **hp)
     cfg = O.OracleConfig(**{kk: v for kk, v in full.items() if kk in O.OracleConfig.__dataclass_fields__})
     cfg.padding_len = Ts
-    cores = os.cpu_count() or 1
+    # host cores this process may use: the 1-GPU box exposes its whole host (256 logical CPUs) but the
+    # job's share is 16; more intra-op threads than that only add synchronisation overhead
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("RNAMPNN_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     cs = torch.from_numpy(coords[:S, :Ts].copy())
     ms = torch.from_numpy(mask[:S, :Ts].copy())

@@ -71,6 +71,7 @@ struct rnampnn_ctx {
     int feat_gn_scale, feat_gn_shift;
     std::vector<Lin> edge_embed;
     size_t edge_embed_img = 0;    // bf16 fragment image for the fast path
+    size_t edge_embed_b1p = 0;    // bias of its second Linear in the kernel's channel order
     std::vector<MpnnLayer> mpnn;
     std::vector<Lin> raw_ffn;
     int rawffn_gn_scale, rawffn_gn_shift;
@@ -180,10 +181,6 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
     if (g.padding_len < 1) return fail(RNAMPNN_ERR_BAD_ARG, "padding_len must be positive");
     if (g.precision != RNAMPNN_PREC_F32 && g.precision != RNAMPNN_PREC_BF16)
         return fail(RNAMPNN_ERR_BAD_ARG, "unknown precision %d", g.precision);
-#ifndef RN_FAST_READY
-    if (g.precision == RNAMPNN_PREC_BF16)
-        return fail(RNAMPNN_ERR_UNSUPPORTED, "this build carries the f32 kernels only");
-#endif
     if (g.precision == RNAMPNN_PREC_BF16 &&
         (g.depth_res_edge_feature != 2 || g.depth_res_mpnn != 2 || g.num_mpnn_edge_layers != 2))
         return fail(RNAMPNN_ERR_UNSUPPORTED, "the bf16 kernels cover the default MLP depth 2 only; use precision f32");
@@ -199,7 +196,8 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
     for (int i = 0; i < g.depth_res_edge_feature; ++i)
         c->edge_embed.push_back(make_lin(c, "res_feature.res_edge_embedding_layers." + std::to_string(3 * i),
                                          i == 0 ? RN_ERAW : RN_D, RN_D, true));
-    c->edge_embed_img = add_der(c, (size_t)(RN_ERAWP + RN_D) * RN_D * sizeof(bf16_t));
+    c->edge_embed_img = add_der(c, (size_t)(4 * 7 + 32) * 1024);
+    c->edge_embed_b1p = add_der(c, RN_D * sizeof(float));
     for (int l = 0; l < g.num_res_mpnn_layers; ++l) {
         MpnnLayer m;
         std::string p = "res_mpnn_layers." + std::to_string(l);
@@ -308,7 +306,7 @@ static void finalize_lin(rnampnn_ctx* c, const Lin& l, hipStream_t s) {
     if (c->cfg.precision == RNAMPNN_PREC_BF16)
         launch_convert_rows_bf16(rawp(c, l.w), l.in, l.out, l.in, l.in_pad, derp<bf16_t>(c, l.wb), s);
 }
-static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, hipStream_t s) {
+static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream_t s) {
     const float* w0 = rawp(c, m.w[0]);                 // [128][384] = [out][h_i | h_j | e]
     float* pq = derp<float>(c, m.pq_t);
     launch_transpose(w0, 3 * RN_D, RN_D, RN_D, pq, 256, s);                    // P part
@@ -320,7 +318,7 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, hipStream_t s) {
         // node GEMM weights [P rows | Q rows] = W0[:, 0:128] and W0[:, 128:256], bf16 [256][128]
         launch_convert_rows_bf16(w0, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb), s);
         launch_convert_rows_bf16(w0 + RN_D, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb) + RN_D * RN_D, s);
-        launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]),
+        launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
                                derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
     }
 }
@@ -338,12 +336,12 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
         for (auto& l : b->ffn) finalize_lin(h, l, s);
     }
     for (auto& l : h->edge_embed) finalize_lin(h, l, s);
-    for (auto& m : h->mpnn) { finalize_mlp2(h, m.msg, s); finalize_mlp2(h, m.edge, s); }
+    for (auto& m : h->mpnn) { finalize_mlp2(h, m.msg, false, s); finalize_mlp2(h, m.edge, true, s); }
     for (auto& l : h->raw_ffn) finalize_lin(h, l, s);
     for (auto& l : h->readout) finalize_lin(h, l, s);
     if (h->cfg.precision == RNAMPNN_PREC_BF16)
-        launch_build_embed_image(rawp(h, h->edge_embed[0].w), rawp(h, h->edge_embed[1].w),
-                                 derp<bf16_t>(h, h->edge_embed_img), s);
+        launch_build_embed_image(rawp(h, h->edge_embed[0].w), rawp(h, h->edge_embed[1].w), rawp(h, h->edge_embed[1].b),
+                                 derp<bf16_t>(h, h->edge_embed_img), derp<float>(h, h->edge_embed_b1p), s);
     HIP_TRY(hipGetLastError());
     h->finalized = true;
     return RNAMPNN_OK;
@@ -549,7 +547,7 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
         return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
     if (r.fast)
         launch_edge_embed_bf16(r.pk, k, w.geom, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
-                               rawp(c, c->edge_embed[1].b), (bf16_t*)w.e, s);
+                               derp<float>(c, c->edge_embed_b1p), (bf16_t*)w.e, s);
     else
         launch_edge_embed_f32(r.pk, k, w.geom, w.nbr, derp<float>(c, c->edge_embed[0].wt), rawp(c, c->edge_embed[0].b),
                               g.depth_res_edge_feature > 1 ? derp<float>(c, c->edge_embed[1].wt) : nullptr,
