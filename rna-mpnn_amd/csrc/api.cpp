@@ -351,6 +351,7 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
 struct Ws {                       // workspace carve (all offsets 256-byte aligned)
     int *len, *cu, *node_b, *nbr;
     float *geom, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
+    bf16_t *q_e, *q_m;            // fast path: bf16 Q tables [(Nmax+1)][128]; pq_* then hold P as [(Nmax+1)][128] f32
     void* e;                      // f32 or bf16 [Nmax*k][128]
     float* big;                   // [Nmax*k][128] f32 scratch for the stage API / edge taps
     size_t total;
@@ -373,13 +374,15 @@ static size_t carve(const rnampnn_ctx* c, int B, int T, char* base, Ws* w) {
     r.hB = (float*)take((Nmax + 1) * RN_D * sizeof(float));
     r.pq_e = (float*)take((Nmax + 1) * 256 * sizeof(float));
     r.pq_m = (float*)take((Nmax + 1) * 256 * sizeof(float));
+    r.q_e = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
+    r.q_m = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
     r.s0 = (float*)take(Nmax * F * sizeof(float));
     r.s1 = (float*)take(Nmax * F * sizeof(float));
     r.n0 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n1 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n2 = (float*)take(Nmax * RN_D * sizeof(float));
     r.logits_p = (float*)take(Nmax * 4 * sizeof(float));
-    r.e = (void*)take(Nmax * k * RN_D * esz);
+    r.e = (void*)take(c->cfg.precision == RNAMPNN_PREC_BF16 ? efrag_bytes((int)Nmax, (int)k) : Nmax * k * RN_D * esz);
     r.big = (float*)take(Nmax * k * RN_D * sizeof(float));
     r.total = off;
     return off;
@@ -407,7 +410,7 @@ static void gemm(Run& r, const Lin& l, const float* X, int ldx, float* Y, int ld
     int k2 = K1 < 0 ? 0 : l.in_pad - K1;
     if (r.fast && l.out >= 64)
         launch_gemm_bf16(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<bf16_t>(c, l.wb), rawp(c, l.b), l.out,
-                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
+                         l.gelu ? 1 : 0, res, ldres, Y, ldy, nullptr, 0, 0, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<float>(c, l.wt), rawp(c, l.b), l.out,
                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
@@ -420,7 +423,7 @@ static int run_bert(Run& r, const Bert& b, float* x, float* out) {
         gemm(r, a.qkv, x, RN_D, r.w.s0, 3 * RN_D);
         if (launch_attention_f32(r.pk, r.w.s0, b.heads, r.w.n2, r.s)) return fail(RNAMPNN_ERR_UNSUPPORTED, "head dim unsupported");
         gemm(r, a.out, r.w.n2, RN_D, r.w.s1, RN_D, x, RN_D);                          // x + out_proj(attn)
-        launch_graph_norm_packed(r.pk, r.w.s1, x, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s);
+        launch_graph_norm_packed(r.pk, r.w.s1, nullptr, x, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s);
     }
     const float* cur = x;
     int ld = RN_D;
@@ -447,11 +450,11 @@ static void run_ffn(Run& r, const std::vector<Lin>& ffn, const float* x, int ldx
     }
 }
 
-static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq) {
+static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq, bf16_t* q) {
     rnampnn_ctx* c = r.c;
-    if (r.fast)
+    if (r.fast)     // P -> f32 [N][128] (in pq), Q -> bf16 [N][128] (in q)
         launch_gemm_bf16(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<bf16_t>(c, m.pq_wb),
-                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
+                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, RN_D, q, RN_D, RN_D, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<float>(c, m.pq_t),
                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
@@ -479,8 +482,8 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size();
     if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
     if (r.fast) {
-        launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.pq_m,
-                         we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_in, h_pre, msg_out, r.s);
+        launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.q_e, r.w.pq_m,
+                         r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, r.s);
     } else {
         MpnnW32 e32 = we ? w32(c, *we) : MpnnW32{}, m32 = wm ? w32(c, *wm) : MpnnW32{};
         launch_mpnn_f32(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (float*)r.w.e, r.w.pq_e, r.w.pq_m, e32, m32,
@@ -492,7 +495,7 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
 static void unpack_e(Run& r, float* dst) {
     int k = r.c->cfg.num_res_neighbours;
     if (r.fast) {
-        launch_bf16_to_f32((const bf16_t*)r.w.e, r.w.big, (size_t)r.pk.Nmax * k * RN_D, r.ntot(), k * RN_D, r.s);
+        launch_efrag_to_rows((const bf16_t*)r.w.e, r.ntot(), r.pk.Nmax, k, r.w.big, r.s);
         launch_unpack_edges(r.pk, k, r.w.big, r.w.nbr, dst, r.s);
     } else {
         launch_unpack_edges(r.pk, k, (const float*)r.w.e, r.w.nbr, dst, r.s);
@@ -521,6 +524,12 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
     HIP_TRY(hipMemsetAsync(r.w.hB + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
     HIP_TRY(hipMemsetAsync(r.w.pq_e + Nmax * 256, 0, 256 * sizeof(float), r.s));
     HIP_TRY(hipMemsetAsync(r.w.pq_m + Nmax * 256, 0, 256 * sizeof(float), r.s));
+    if (r.fast) {   // fast-path tables are [N+1][128]: P f32 inside pq_*, Q bf16
+        HIP_TRY(hipMemsetAsync(r.w.pq_e + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
+        HIP_TRY(hipMemsetAsync(r.w.pq_m + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
+        HIP_TRY(hipMemsetAsync(r.w.q_e + Nmax * RN_D, 0, RN_D * sizeof(bf16_t), r.s));
+        HIP_TRY(hipMemsetAsync(r.w.q_m + Nmax * RN_D, 0, RN_D * sizeof(bf16_t), r.s));
+    }
     return RNAMPNN_OK;
 }
 
@@ -556,21 +565,23 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
     gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
     rc = run_bert(r, c->emb, w.n0, w.n1);
     if (rc) return rc;
-    launch_graph_norm_packed(r.pk, w.n1, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
+    launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
     if (io->h0) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h0, s);
     if (io->e0) unpack_e(r, io->e0);
     if (io->stop_after == 1) { HIP_TRY(hipGetLastError()); return RNAMPNN_OK; }
 
     // ---- L x ResMPNN.forward (mpnn.py:283-294), edge update of layer l fused with the message of l+1
-    node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m);
+    node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m, w.q_m);
     bool edge_pending = false;                                 // layer l-1's edge update not yet applied
     for (int l = 0; l < L; ++l) {
         mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr);
-        launch_graph_norm_packed(r.pk, w.hB, w.hA, rawp(c, c->mpnn[l].gn_scale), rawp(c, c->mpnn[l].gn_shift), t_norm, s);
+        // f32 kernels write h + agg; the bf16 kernel writes agg and the norm kernel takes the residual
+        launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, rawp(c, c->mpnn[l].gn_scale),
+                                 rawp(c, c->mpnn[l].gn_shift), t_norm, s);
         bool tap_e = io->tap_layer == l + 1 && io->e_layer;
         edge_pending = l + 1 < L;                              // layer L's edge update is dead work
-        if (edge_pending || tap_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e);
-        if (l + 1 < L) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m);
+        if (edge_pending || tap_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e, w.q_e);
+        if (l + 1 < L) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m, w.q_m);
         if (io->tap_layer == l + 1) {
             if (io->h_layer) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h_layer, s);
             if (tap_e) {
@@ -584,7 +595,7 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
     rc = run_bert(r, c->post, w.hA, w.n0);                     // h_post -> n0
     if (rc) return rc;
     run_ffn(r, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
-    launch_graph_norm_packed(r.pk, w.n1, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
+    launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
     if (io->h_post) launch_unpack_nodes(r.pk, w.n0, RN_D, RN_D, io->h_post, s);
     if (io->raw_emb) launch_unpack_nodes(r.pk, w.n2, RN_D, RN_D, io->raw_emb, s);
     if (io->embedding) {
@@ -627,20 +638,20 @@ extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* 
     launch_pack_index(r.pk, k, edge_index, w.nbr, s);
     if (r.fast) {
         launch_pack_edges(r.pk, k, e_in, w.big, s);
-        launch_f32_to_bf16(w.big, (bf16_t*)w.e, (size_t)r.pk.Nmax * k * RN_D, r.ntot(), k * RN_D, s);
+        launch_rows_to_efrag(w.big, r.ntot(), r.pk.Nmax, k, (bf16_t*)w.e, s);
     } else {
         launch_pack_edges(r.pk, k, e_in, (float*)w.e, s);
     }
     const MpnnLayer& m = c->mpnn[layer];
-    node_pq(r, m.msg, w.hA, w.pq_m);
+    node_pq(r, m.msg, w.hA, w.pq_m, w.q_m);
     float* msg_p = msg_out ? w.big : nullptr;
     mpnn_step(r, nullptr, &m.msg, w.hA, w.hB, msg_p);
     if (msg_out) launch_unpack_edges(r.pk, k, w.big, nullptr, msg_out, s);
     if (h_out || e_out) {
-        launch_graph_norm_packed(r.pk, w.hB, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
+        launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
         if (h_out) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, h_out, s);
         if (e_out) {
-            node_pq(r, m.edge, w.hA, w.pq_e);
+            node_pq(r, m.edge, w.hA, w.pq_e, w.q_e);
             mpnn_step(r, &m.edge, nullptr, w.hA, w.hB, nullptr);
             unpack_e(r, e_out);
         }
@@ -684,7 +695,7 @@ extern "C" int rnampnn_raw_ffn(rnampnn_handle h, const float* raw, const float* 
     HIP_TRY(hipMemsetAsync(r.w.raw_p, 0, (size_t)r.pk.Nmax * RN_RAWP * sizeof(float), r.s));
     launch_pack_nodes(r.pk, raw, RN_RAW, r.w.raw_p, RN_RAWP, r.s);
     run_ffn(r, h->raw_ffn, r.w.raw_p, RN_RAWP, r.w.n1);
-    launch_graph_norm_packed(r.pk, r.w.n1, r.w.n2, rawp(h, h->rawffn_gn_scale), rawp(h, h->rawffn_gn_shift),
+    launch_graph_norm_packed(r.pk, r.w.n1, nullptr, r.w.n2, rawp(h, h->rawffn_gn_scale), rawp(h, h->rawffn_gn_shift),
                              T_norm > 0 ? T_norm : T, r.s);
     launch_unpack_nodes(r.pk, r.w.n2, RN_D, RN_D, y, r.s);
     HIP_TRY(hipGetLastError());

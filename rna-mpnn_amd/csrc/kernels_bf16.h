@@ -13,15 +13,18 @@ void launch_convert_rows_bf16(const float* src, int ld_src, int rows, int cols, 
 void launch_build_mlp_image(const float* wc, int ld_wc, const float* w2, int ld_w2, const float* b2, int out_perm,
                             bf16_t* img, float* b2p, hipStream_t s);
 void launch_build_embed_image(const float* w0, const float* w1, const float* b1, bf16_t* img, float* b1p, hipStream_t s);
-// element conversion of packed edge rows (stage API / taps)
-void launch_bf16_to_f32(const bf16_t* src, float* dst, size_t max_elems, const int* ntot, int per_row, hipStream_t s);
-void launch_f32_to_bf16(const float* src, bf16_t* dst, size_t max_elems, const int* ntot, int per_row, hipStream_t s);
+// the bf16 edge tensor is stored fragment-major (8 KiB per 32-slot block, see kernels_bf16.hip);
+// conversion to / from row-major f32 rows [(p*k + slot)][128] for taps and the stage API
+void launch_efrag_to_rows(const bf16_t* ef, const int* ntot, int nmax, int k, float* rows, hipStream_t s);
+void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, bf16_t* ef, hipStream_t s);
+static inline size_t efrag_bytes(int nmax, int k) { int npb = k > 16 ? 1 : 32 / k; return (size_t)((nmax + npb - 1) / npb) * 8192; }
 // node-level Linear on MFMA: Y = act([X | X2] . W^T + bias) (+ res);  W bf16 [N][K] row-major
 void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
                       const bf16_t* W, const float* bias, int N, int act, const float* res, int ldres,
-                      float* Y, int ldy, hipStream_t s);
+                      float* Y, int ldy, bf16_t* Yb, int ldyb, int col_split, hipStream_t s);   // cols >= col_split -> bf16 Yb (if Yb)
 void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const int* nbr, const bf16_t* img,
                             const float* b0, const float* b1p, bf16_t* e, hipStream_t s);
+// node tables: p_* f32 [N+1][128] (h.Wa^T + b1), q_* bf16 [N+1][128] (h.Wb^T; row Nmax = zeros)
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
-                      const float* pq_e, const float* pq_m, MpnnWB we, MpnnWB wm, const float* h_in,
-                      float* h_pre, float* msg_out, hipStream_t s);
+                      const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
+                      float* agg, float* msg_out, hipStream_t s);   // agg [N][128]: masked mean of the messages (no residual)

@@ -18,6 +18,7 @@
 // Weights live in LDS as ready-made 1 KiB MFMA fragments (lane-linear, conflict-free
 // ds_read_b128); a 512-thread workgroup per CU loads them once and then walks 32-edge blocks.
 #include "kernels_bf16.h"
+#include <cstdio>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -150,20 +151,45 @@ void launch_build_embed_image(const float* w0, const float* w1, const float* b1,
     hipLaunchKernelGGL(k_build_embed_image, dim3((total + 255) / 256), dim3(256), 0, s, w0, w1, b1, img, b1p);
 }
 
-__global__ void k_bf16_to_f32(const bf16_t* __restrict__ src, float* __restrict__ dst, const int* __restrict__ ntot, int per_row) {
-    size_t n = (size_t)(*ntot) * per_row;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
+// fragment-major bf16 e  <->  row-major f32 rows [(p*k + slot)][128]  (taps and the stage API only)
+__global__ void k_efrag_to_rows(const bf16_t* __restrict__ ef, const int* __restrict__ ntot_p, int k, float* __restrict__ rows) {
+    const int ntot = *ntot_p;
+    const int npb = k > 16 ? 1 : 32 / k;
+    const size_t total = (size_t)ntot * k * 16;            // one 8-channel chunk per thread
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(id & 15);
+        const size_t row = id >> 4;
+        const int p = (int)(row / k), sl = (int)(row - (size_t)p * k);
+        const int blk = p / npb, r = (p - blk * npb) * k + sl;
+        const int s = c8 >> 1, h = c8 & 1;
+        const bf16_t* src = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
+        float* dst = rows + row * RN_D + 8 * c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = bf2f(src[j]);
+    }
 }
-__global__ void k_f32_to_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, const int* __restrict__ ntot, int per_row) {
-    size_t n = (size_t)(*ntot) * per_row;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+__global__ void k_rows_to_efrag(const float* __restrict__ rows, const int* __restrict__ ntot_p, int k, bf16_t* __restrict__ ef) {
+    const int ntot = *ntot_p;
+    const int npb = k > 16 ? 1 : 32 / k;
+    const size_t total = (size_t)ntot * k * 16;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(id & 15);
+        const size_t row = id >> 4;
+        const int p = (int)(row / k), sl = (int)(row - (size_t)p * k);
+        const int blk = p / npb, r = (p - blk * npb) * k + sl;
+        const int s = c8 >> 1, h = c8 & 1;
+        bf16_t* dst = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
+        const float* src = rows + row * RN_D + 8 * c8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = f2bf(src[j]);
+    }
 }
 static unsigned conv_grid(size_t max_elems) { size_t g = (max_elems + 255) / 256; return (unsigned)(g < 8192 ? (g ? g : 1) : 8192); }
-void launch_bf16_to_f32(const bf16_t* src, float* dst, size_t max_elems, const int* ntot, int per_row, hipStream_t s) {
-    hipLaunchKernelGGL(k_bf16_to_f32, dim3(conv_grid(max_elems)), dim3(256), 0, s, src, dst, ntot, per_row);
+void launch_efrag_to_rows(const bf16_t* ef, const int* ntot, int nmax, int k, float* rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_efrag_to_rows, dim3(conv_grid((size_t)nmax * k * 16)), dim3(256), 0, s, ef, ntot, k, rows);
 }
-void launch_f32_to_bf16(const float* src, bf16_t* dst, size_t max_elems, const int* ntot, int per_row, hipStream_t s) {
-    hipLaunchKernelGGL(k_f32_to_bf16, dim3(conv_grid(max_elems)), dim3(256), 0, s, src, dst, ntot, per_row);
+void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, bf16_t* ef, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_to_efrag, dim3(conv_grid((size_t)nmax * k * 16)), dim3(256), 0, s, rows, ntot, k, ef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -173,8 +199,14 @@ struct BlockLane {            // what one lane knows about its edge in the curre
     int j;                    // packed neighbour row (or -1)
     bool ok;                  // lane maps to an existing (residue, slot)
     bool valid;               // ... and the slot holds an edge
-    size_t erow;              // row of e / nbr
+    size_t erow;              // row of nbr (and of the row-major e of the API / f32 path)
 };
+// The bf16 edge tensor lives in HBM in FRAGMENT-MAJOR order: block b (32 edge slots) is 8 KiB =
+// [k-step s 0..7][lane 0..63][8 bf16], i.e. exactly the register image of the B fragments, so every
+// load/store instruction of the edge kernels moves one fully contiguous 1 KiB.
+__device__ __forceinline__ u32x4* efrag_ptr(bf16_t* e, int blk, int lane) {
+    return reinterpret_cast<u32x4*>(e) + (size_t)blk * 512 + lane;
+}
 
 __device__ __forceinline__ BlockLane block_lane(int blk, int npb, int k, int ntot, int r, const int* __restrict__ nbr) {
     BlockLane b;
@@ -188,18 +220,6 @@ __device__ __forceinline__ BlockLane block_lane(int blk, int npb, int k, int nto
     return b;
 }
 
-// acc = P[node][32mb+16h..+16] + Q[j][..]  (first Linear's node parts; rows are [P | Q], 256 wide)
-__device__ __forceinline__ f32x16 init_pq(const float* __restrict__ pp, const float* __restrict__ qp, int mb) {
-    f32x16 acc;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(pp + 32 * mb + 4 * v);
-        f32x4 b = *reinterpret_cast<const f32x4*>(qp + 32 * mb + 4 * v);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[4 * v + t] = a[t] + b[t];
-    }
-    return acc;
-}
 __device__ __forceinline__ f32x16 init_vec16(const float* __restrict__ p) {
     f32x16 acc;
 #pragma unroll
@@ -220,14 +240,23 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
     }
 }
 
-// First Linear (+GELU) of an e-MLP: hb[2mb + s'] = bf16(GELU(P + Q + Wc . e))   [channel blocks mb]
+// First Linear (+GELU) of an e-MLP: hb[2mb + s'] = bf16(GELU(P[i] + Q[j] + Wc . e)), channel blocks mb.
+// P row (f32, the same address for every lane of a half: a broadcast load) initialises the
+// accumulator; the gathered Q row arrives as bf16 in qv[2mb], qv[2mb+1] (prefetched by the caller).
 __device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lane, const u32x4 (&ef)[8],
-                                          const float* __restrict__ pp, const float* __restrict__ qp, u32x4 (&hb)[8]) {
+                                          const float* __restrict__ pp, const u32x4 (&qv)[8], u32x4 (&hb)[8]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        f32x16 acc = init_pq(pp, qp, mb);
+        f32x16 acc = init_vec16(pp + 32 * mb);
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc = mfma32(img[(mb * 8 + s) * 64 + lane], ef[s], acc);
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[8 * v + 2 * t] += lo_bf(qv[2 * mb + v][t]);
+                acc[8 * v + 2 * t + 1] += hi_bf(qv[2 * mb + v][t]);
+            }
         gelu_pack(acc, hb[2 * mb], hb[2 * mb + 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -236,45 +265,119 @@ __device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lan
 // ------------------------------------------------------------------------------------------
 // Fused ResMPNN step on 32-edge blocks (mpnn.py:154-265), bf16 MFMA:
 //   DO_EDGE: e <- e + MLP_e(P_e[i] + Q_e[j] + e Wc_e)   (edge update of the previous layer)
-//   DO_MSG : h_pre = h + mean_valid MLP_m(P_m[i] + Q_m[j] + e Wc_m)   (message + aggregation)
+//   DO_MSG : agg = mean_valid MLP_m(P_m[i] + Q_m[j] + e Wc_m)   (message + aggregation; the residual
+//            h + agg of mpnn.py:222 is taken by the graph-norm kernel that follows)
 // One wave owns one block: lanes (r, h) = (edge r of the block, k-half h).  k <= 16 packs
 // npb = 32/k residues into a block (edges of consecutive residues are contiguous in e).
-template <bool DO_EDGE, bool DO_MSG>
+// Software pipeline per wave: the neighbour indices of the next block are fetched at the top of
+// a block, its e fragments after the first Linear; the Q gathers of a block are issued at its top.
+#ifdef RN_STAMPS   // diagnostic build only: per-phase cycle shares of the fused kernel (never shipped enabled)
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_ACC(idx, t0, t1) do { phase[idx] += (t1) - (t0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#define STAMP_ACC(idx, t0, t1) do { } while (0)
+#endif
+struct NodeTabs {             // per-residue parts of the first Linears (node GEMM outputs)
+    const float* p_e;         // [N+1][128] f32   h.Wa_e^T + b1_e
+    const bf16_t* q_e;        // [N+1][128] bf16  h.Wb_e^T         (row N = zeros)
+    const float* p_m;
+    const bf16_t* q_m;
+    unsigned long long* dbg;  // RN_STAMPS diagnostic buffer (null otherwise)
+};
+
+template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
 __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
-        const float* __restrict__ pq_e, const float* __restrict__ pq_m, MpnnWB we, MpnnWB wm,
-        const float* __restrict__ h_in, float* __restrict__ h_pre, float* __restrict__ msg_out) {
+        NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
+    // LDS: [img_e 64 KiB][img_m 64 KiB][b2 of edge MLP 512 B][b2 of message MLP 512 B][per wave: P_e | P_m rows, 1 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
-    u32x4* img_m = img_e + (DO_EDGE ? 4096 : 0);
+    u32x4* img_m = img_e + 4096;
+    float* lds_b2e = reinterpret_cast<float*>(smem + 131072);
+    float* lds_b2m = lds_b2e + 128;
     const int tid = threadIdx.x;
+    float* lds_p = lds_b2m + 128 + (tid >> 6) * 256;
     if (DO_EDGE) for (int i = tid; i < 4096; i += 512) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
     if (DO_MSG) for (int i = tid; i < 4096; i += 512) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
+    if (tid < 128) { lds_b2e[tid] = DO_EDGE ? we.b2p[tid] : 0.f; lds_b2m[tid] = DO_MSG ? wm.b2p[tid] : 0.f; }
     __syncthreads();
 
     const int ntot = pk.cu[pk.B];
-    const int npb = k > 16 ? 1 : 32 / k;
+    const int npb = SMALLK ? 32 / k : 1;              // SMALLK <=> k <= 16
     const int nblocks = (ntot + npb - 1) / npb;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int zero_row = pk.Nmax;
+    const int stride = gridDim.x * 8;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    for (int blk = blockIdx.x * 8 + wave; blk < nblocks; blk += gridDim.x * 8) {
-        BlockLane bl = block_lane(blk, npb, k, ntot, r, nbr);
+    int blk = blockIdx.x * 8 + wave;
+    if (blk >= nblocks) return;
+    BlockLane bl = block_lane(blk, npb, k, ntot, r, nbr);
+    u32x4 ef[8];
+    f32x2 pe_n = {0.f, 0.f}, pm_n = {0.f, 0.f};        // this block's P rows (2 floats per lane), !SMALLK only
+    if (!SMALLK) {
+        if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)blk * RN_D + 2 * lane);
+        if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)blk * RN_D + 2 * lane);
+    }
+    {
+        const u32x4* erp = efrag_ptr(e, blk, lane);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ef[s] = bl.ok ? erp[64 * s] : zero4;
+    }
+#ifdef RN_STAMPS
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+#endif
+    while (true) {
+        STAMP(t0);
+        const int nblk = blk + stride;
+        const bool has_next = nblk < nblocks;
         const int prow = bl.ok ? bl.node : zero_row;
         const int qrow = bl.valid ? (bl.j > zero_row ? zero_row : bl.j) : zero_row;    // phantom -> zero row
-        u32x4 ef[8];
-        const u32x4* erp = reinterpret_cast<const u32x4*>(e + bl.erow * RN_D + 8 * h);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) ef[s] = bl.ok ? erp[2 * s] : u32x4{0u, 0u, 0u, 0u};
-
-        u32x4 hb[8];
+        // gather of this block's Q_e row (bf16, 2 x 16 B per channel block) and the next block's indices
+        u32x4 qe[8], qm[8];
         if (DO_EDGE) {
-            mlp_first(img_e, lane, ef, pq_e + (size_t)prow * 256 + 16 * h, pq_e + (size_t)qrow * 256 + 128 + 16 * h, hb);
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_e + (size_t)qrow * RN_D + 16 * h);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { qe[2 * mb] = qp[4 * mb]; qe[2 * mb + 1] = qp[4 * mb + 1]; }
+        }
+        BlockLane bn = bl;
+        if (has_next) bn = block_lane(nblk, npb, k, ntot, r, nbr);
+        if (!SMALLK) {      // one residue per block: its P rows go through a wave-private LDS slot (broadcast reads)
+            if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = pe_n;
+            if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = pm_n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        u32x4 hb[8], efn[8];
+        STAMP(t1);
+        if (DO_EDGE) {
+            mlp_first(img_e, lane, ef, SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : lds_p + 16 * h, qe, hb);
+        }
+        STAMP(t2);
+        // Q_m gather and the next block's e fragments: in flight during the following Linear(s)
+        if (DO_MSG) {
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D + 16 * h);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { qm[2 * mb] = qp[4 * mb]; qm[2 * mb + 1] = qp[4 * mb + 1]; }
+        }
+        {
+            const u32x4* erp = efrag_ptr(e, has_next ? nblk : blk, lane);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) efn[s] = (has_next && bn.ok) ? erp[64 * s] : zero4;
+            if (!SMALLK && has_next) {
+                if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nblk * RN_D + 2 * lane);
+                if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nblk * RN_D + 2 * lane);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t3);
+        if (DO_EDGE) {
             // second Linear, rows in the e fragment layout: registers 0..7 of block ob <-> ef[2ob], 8..15 <-> ef[2ob+1]
             const bool wr = bl.ok && bl.valid;
-            u32x4* ewp = reinterpret_cast<u32x4*>(e + bl.erow * RN_D + 8 * h);
+            u32x4* ewp = efrag_ptr(e, blk, lane);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
-                f32x16 acc = init_vec16(we.b2p + 32 * ob + 16 * h);
+                f32x16 acc = init_vec16(lds_b2e + 32 * ob + 16 * h);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) acc = mfma32(img_e[2048 + (ob * 8 + ks) * 64 + lane], hb[ks], acc);
 #pragma unroll
@@ -284,18 +387,20 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
                     for (int t = 0; t < 4; ++t)
                         nw[t] = pack2(lo_bf(old[t]) + gelu_fast(acc[8 * sp + 2 * t]),
                                       hi_bf(old[t]) + gelu_fast(acc[8 * sp + 2 * t + 1]));
-                    if (wr) { ef[2 * ob + sp] = nw; ewp[2 * (2 * ob + sp)] = nw; }
+                    if (wr) { ef[2 * ob + sp] = nw; ewp[64 * (2 * ob + sp)] = nw; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(t4);
         if (DO_MSG) {
-            mlp_first(img_m, lane, ef, pq_m + (size_t)prow * 256 + 16 * h, pq_m + (size_t)qrow * 256 + 128 + 16 * h, hb);
+            mlp_first(img_m, lane, ef, SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : lds_p + 128 + 16 * h, qm, hb);
+            STAMP(t5);
             const unsigned vmask = (unsigned)(__ballot(bl.ok && bl.valid) & 0xffffffffull);   // bit r = edge r is real
             // last Linear un-transposed: rows = edges of the block (registers), columns = channels 32nb + r
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const float b = wm.b2p[32 * nb + r];
+                const float b = lds_b2m[32 * nb + r];
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = b;
@@ -303,7 +408,7 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
                 for (int ks = 0; ks < 8; ++ks) acc = mfma32(hb[ks], img_m[2048 + (nb * 8 + ks) * 64 + lane], acc);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = gelu_fast(acc[i]);
-                if (msg_out) {
+                if (MSGOUT) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int er = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -312,10 +417,10 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
                             msg_out[((size_t)blk * npb * k + er) * RN_D + 32 * nb + r] = acc[i] * (float)((vmask >> er) & 1u);
                     }
                 }
-                for (int q = 0; q < npb; ++q) {
+                for (int q = 0; q < (SMALLK ? npb : 1); ++q) {
                     const int node = blk * npb + q;
                     if (node >= ntot) break;
-                    const unsigned seg = npb == 1 ? vmask : (vmask & (((1u << k) - 1u) << (q * k)));
+                    const unsigned seg = SMALLK ? (vmask & (((1u << k) - 1u) << (q * k))) : vmask;
                     const unsigned segh = seg >> (4 * h);
                     float sum = 0.f;
 #pragma unroll
@@ -323,15 +428,27 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
                         sum = fmaf(acc[i], (float)((segh >> ((i & 3) + 8 * (i >> 2))) & 1u), sum);
                     sum += __shfl_xor(sum, 32, 64);
                     const int cnt = __popc(seg);
-                    if (h == 0) {
-                        const size_t o = (size_t)node * RN_D + 32 * nb + r;
-                        h_pre[o] = h_in[o] + sum / (float)(cnt > 0 ? cnt : 1);
-                    }
+                    if (h == 0) agg[(size_t)node * RN_D + 32 * nb + r] = sum / (float)(cnt > 0 ? cnt : 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(t6);
+        STAMP_ACC(0, t0, t1); STAMP_ACC(1, t1, t2); STAMP_ACC(2, t2, t3); STAMP_ACC(3, t3, t4);
+        STAMP_ACC(4, t4, t5); STAMP_ACC(5, t5, t6); STAMP_ACC(6, t0, t6);
+#ifdef RN_STAMPS
+        phase[7] += 1;
+#endif
+        if (!has_next) break;
+        blk = nblk;
+        bl = bn;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ef[s] = efn[s];
     }
+#ifdef RN_STAMPS
+    if (tab.dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(tab.dbg + i, phase[i]);
+#endif
 }
 
 static int num_cus() {
@@ -346,27 +463,46 @@ static int num_cus() {
 }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
-                      const float* pq_e, const float* pq_m, MpnnWB we, MpnnWB wm, const float* h_in,
-                      float* h_pre, float* msg_out, hipStream_t s) {
+                      const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
+                      float* agg, float* msg_out, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
     int grid = (max_blocks + 7) / 8;
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
-    size_t lds = (size_t)((do_edge ? 1 : 0) + (do_msg ? 1 : 0)) * 65536;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr_done = true;
+    size_t lds = 131072 + 1024 + 8 * 1024;
+    NodeTabs tab{p_e, q_e, p_m, q_m, nullptr};
+#ifdef RN_STAMPS
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc((void**)&dbg, 64);
+    (void)hipMemsetAsync(dbg, 0, 64, s);
+    tab.dbg = dbg;
+#endif
+    const bool smallk = k <= 16, mo = msg_out != nullptr;
+#define RN_LAUNCH(E, M, S, O)                                                                                  \
+    do {                                                                                                       \
+        static bool done = false;                                                                              \
+        if (!done) {                                                                                           \
+            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024 + 8192); \
+            done = true;                                                                                       \
+        }                                                                                                      \
+        hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(512), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
+    } while (0)
+    if (do_edge && do_msg) { if (smallk) RN_LAUNCH(true, true, true, false); else RN_LAUNCH(true, true, false, false); }
+    else if (do_edge)      { if (smallk) RN_LAUNCH(true, false, true, false); else RN_LAUNCH(true, false, false, false); }
+    else if (mo)           { if (smallk) RN_LAUNCH(false, true, true, true); else RN_LAUNCH(false, true, false, true); }
+    else                   { if (smallk) RN_LAUNCH(false, true, true, false); else RN_LAUNCH(false, true, false, false); }
+#undef RN_LAUNCH
+#ifdef RN_STAMPS
+    unsigned long long hst[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(hst, dbg, 64, hipMemcpyDeviceToHost);
+    if (hst[7]) {
+        fprintf(stderr, "[stamps e=%d m=%d] blocks %llu cycles/block: top %.0f E1 %.0f issue %.0f E2 %.0f M1 %.0f M2 %.0f total %.0f\n",
+                (int)do_edge, (int)do_msg, hst[7], (double)hst[0] / hst[7], (double)hst[1] / hst[7], (double)hst[2] / hst[7],
+                (double)hst[3] / hst[7], (double)hst[4] / hst[7], (double)hst[5] / hst[7], (double)hst[6] / hst[7]);
     }
-    if (do_edge && do_msg)
-        hipLaunchKernelGGL((k_mpnn_bf16<true, true>), dim3(grid), dim3(512), lds, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
-    else if (do_edge)
-        hipLaunchKernelGGL((k_mpnn_bf16<true, false>), dim3(grid), dim3(512), lds, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
-    else
-        hipLaunchKernelGGL((k_mpnn_bf16<false, true>), dim3(grid), dim3(512), lds, s, pk, k, nbr, e, pq_e, pq_m, we, wm, h_in, h_pre, msg_out);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -442,7 +578,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
             gelu_pack(acc, hb[2 * mb], hb[2 * mb + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        u32x4* ewp = reinterpret_cast<u32x4*>(e + bl.erow * RN_D + 8 * h);
+        u32x4* ewp = efrag_ptr(e, blk, lane);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             f32x16 acc = init_vec16(b1p + 32 * ob + 16 * h);
@@ -455,7 +591,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         nw[t] = bl.valid ? pack2(gelu_fast(acc[8 * sp + 2 * t]), gelu_fast(acc[8 * sp + 2 * t + 1])) : 0u;
-                    ewp[2 * (2 * ob + sp)] = nw;
+                    ewp[64 * (2 * ob + sp)] = nw;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -483,7 +619,8 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
 #define GB_LD 72
 __global__ void __launch_bounds__(256) k_gemm_bf16(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx, int K1,
         const float* __restrict__ X2, int ldx2, int K2, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-        int N, int act, const float* __restrict__ res, int ldres, float* __restrict__ Y, int ldy) {
+        int N, int act, const float* __restrict__ res, int ldres, float* __restrict__ Y, int ldy,
+        bf16_t* __restrict__ Yb, int ldyb, int col_split) {
     __shared__ __attribute__((aligned(16))) bf16_t As[128 * GB_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * GB_LD];
     const int ntot = *ntot_p;
@@ -567,7 +704,8 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(const int* __restrict__ ntot_
                     float v = acc[a][b][i] + bv;
                     if (act == 1) v = gelu_erf(v);
                     if (res) v += res[(size_t)row * ldres + col];
-                    Y[(size_t)row * ldy + col] = v;
+                    if (Yb && col >= col_split) Yb[(size_t)row * ldyb + (col - col_split)] = f2bf(v);
+                    else Y[(size_t)row * ldy + col] = v;
                 }
             }
     }
@@ -575,7 +713,8 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(const int* __restrict__ ntot_
 
 void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
                       const bf16_t* W, const float* bias, int N, int act, const float* res, int ldres,
-                      float* Y, int ldy, hipStream_t s) {
+                      float* Y, int ldy, bf16_t* Yb, int ldyb, int col_split, hipStream_t s) {
     dim3 grid((mmax + 127) / 128, (N + 127) / 128);
-    hipLaunchKernelGGL(k_gemm_bf16, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, W, bias, N, act, res, ldres, Y, ldy);
+    hipLaunchKernelGGL(k_gemm_bf16, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, W, bias, N, act, res, ldres, Y, ldy,
+                       Yb, ldyb, col_split);
 }

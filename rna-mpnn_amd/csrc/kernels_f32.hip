@@ -491,35 +491,66 @@ void launch_mpnn_f32(const PackInfo& pk, int k, bool do_edge, bool do_msg, const
 // GraphNormalization on packed rows (functional.py:18-48), D = 128, one workgroup per RNA:
 //   mu = sum_valid x / n ;  var = [sum_valid (x-mu)^2 + (T_tot - n) mu^2] / n
 //   y = (x - mu) / sqrt(var + 1e-6) * scale + shift         (padded rows do not exist here)
-__global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const float* __restrict__ x, float* __restrict__ y,
-        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot) {
-    __shared__ float red[256];
+// x may come as x + add (the residual h + agg of mpnn.py:222 on the bf16 path).  Thread layout:
+// 32 channel quads (float4) x 8 row groups; the three passes re-read the L2-resident rows.
+__global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int t_tot) {
+    __shared__ float4 red[8][32];
+    __shared__ float4 stat[32];
     int b = blockIdx.x;
     int n = pk.len[b];
     if (n <= 0) return;
-    int base = pk.cu[b];
-    int c = threadIdx.x & 127, hf = threadIdx.x >> 7;
-    const float* xb = x + (size_t)base * RN_D;
-    float s = 0.f;
-    for (int r = hf; r < n; r += 2) s += xb[(size_t)r * RN_D + c];
-    red[threadIdx.x] = s;
+    const size_t base = (size_t)pk.cu[b] * RN_D;
+    const int cq = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
+    const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
+    auto ld = [&](int r) {
+        float4 v = xb[(size_t)r * 32];
+        if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        return v;
+    };
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = g; r < n; r += 8) { float4 v = ld(r); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    red[g][cq] = s;
     __syncthreads();
-    float mean = (red[c] + red[c + 128]) / (float)n;
+    if (g == 0) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { float4 u = red[i][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float inv = 1.0f / (float)n;
+        stat[cq] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
     __syncthreads();
-    float ss = 0.f;
-    for (int r = hf; r < n; r += 2) { float d = xb[(size_t)r * RN_D + c] - mean; ss = fmaf(d, d, ss); }
-    red[threadIdx.x] = ss;
+    const float4 mean = stat[cq];
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = g; r < n; r += 8) {
+        float4 v = ld(r);
+        float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+        ss.x = fmaf(dx, dx, ss.x); ss.y = fmaf(dy, dy, ss.y); ss.z = fmaf(dz, dz, ss.z); ss.w = fmaf(dw, dw, ss.w);
+    }
     __syncthreads();
-    float var = (red[c] + red[c + 128] + (float)(t_tot - n) * mean * mean) / (float)n;
-    float sd = sqrtf(var + kSEPS);
-    float sc = scale[c], sh = shift[c];
-    float* yb = y + (size_t)base * RN_D;
-    for (int r = hf; r < n; r += 2) yb[(size_t)r * RN_D + c] = (xb[(size_t)r * RN_D + c] - mean) / sd * sc + sh;
+    red[g][cq] = ss;
+    __syncthreads();
+    float4 t = red[0][cq];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { float4 u = red[i][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    const float pad = (float)(t_tot - n), fn = (float)n;
+    float4 sd;
+    sd.x = sqrtf((t.x + pad * mean.x * mean.x) / fn + kSEPS); sd.y = sqrtf((t.y + pad * mean.y * mean.y) / fn + kSEPS);
+    sd.z = sqrtf((t.z + pad * mean.z * mean.z) / fn + kSEPS); sd.w = sqrtf((t.w + pad * mean.w * mean.w) / fn + kSEPS);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+    float4* yb = reinterpret_cast<float4*>(y + base) + cq;
+    for (int r = g; r < n; r += 8) {
+        float4 v = ld(r), o;
+        o.x = (v.x - mean.x) / sd.x * sc.x + sh.x; o.y = (v.y - mean.y) / sd.y * sc.y + sh.y;
+        o.z = (v.z - mean.z) / sd.z * sc.z + sh.z; o.w = (v.w - mean.w) / sd.w * sc.w + sh.w;
+        yb[(size_t)r * 32] = o;
+    }
 }
 
-void launch_graph_norm_packed(const PackInfo& pk, const float* x, float* y, const float* scale, const float* shift,
-                              int t_tot, hipStream_t s) {
-    hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, y, scale, shift, t_tot);
+void launch_graph_norm_packed(const PackInfo& pk, const float* x, const float* add, float* y, const float* scale,
+                              const float* shift, int t_tot, hipStream_t s) {
+    hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
 }
 
 // Stand-alone GraphNormalization on the reference's padded layout, any D, mask by value.

@@ -41,8 +41,9 @@ struct MpnnW32 {             // one MLP of a ResMPNN layer in the f32 layouts
 void launch_mpnn_f32(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr,
                      float* e, const float* pq_e, const float* pq_m, MpnnW32 we, MpnnW32 wm,
                      const float* h_in, float* h_pre, float* msg_out, hipStream_t s);
-void launch_graph_norm_packed(const PackInfo& pk, const float* x, float* y, const float* scale, const float* shift,
-                              int t_tot, hipStream_t s);
+// y = GraphNorm(x (+ add)) on packed rows; add may be null; y may alias x or add
+void launch_graph_norm_packed(const PackInfo& pk, const float* x, const float* add, float* y, const float* scale,
+                              const float* shift, int t_tot, hipStream_t s);
 void launch_graph_norm_padded(const float* x, const float* mask, const float* scale, const float* shift,
                               int B, int T, int t_tot, int D, float* y, hipStream_t s);
 // Y[p][0:N] = act(X[p][0:K1] . Wt[0:K1] + X2[p][0:K2] . Wt[K1:K1+K2] + bias) (+ res[p])   for p < *ntot
