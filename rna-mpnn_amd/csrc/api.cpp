@@ -44,8 +44,14 @@ struct Lin {                  // nn.Linear
     size_t wb;                // derived: bf16 [out][in_pad] (fast path), or (size_t)-1
     bool gelu;
 };
+struct Chain {                // fused FFN chain of the fast path (kernels_bf16.hip: k_ffn_chain)
+    bool ok = false;
+    int K0 = 0, H = 0, NH = 0, NOUT = 0, n_valid = 0;
+    size_t img = 0;           // derived: fragment image of all layers
+    size_t last_bias = 0;     // derived: bias of the last Linear padded to NOUT
+};
 struct Attn { Lin qkv, out; int gn_scale, gn_shift; };
-struct Bert { std::vector<Attn> attn; std::vector<Lin> ffn; int heads; };
+struct Bert { std::vector<Attn> attn; std::vector<Lin> ffn; int heads; Chain chain; };
 struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     int depth;
     int w[2], b[2];           // RawT indices
@@ -74,8 +80,10 @@ struct rnampnn_ctx {
     size_t edge_embed_b1p = 0;    // bias of its second Linear in the kernel's channel order
     std::vector<MpnnLayer> mpnn;
     std::vector<Lin> raw_ffn;
+    Chain raw_chain;
     int rawffn_gn_scale, rawffn_gn_shift;
     std::vector<Lin> readout;
+    Chain readout_chain;
     int fmax = 0;                 // widest node activation
     // optional live timing of the dominant kernel (bench.py roofline leg)
     bool prof = false;
@@ -110,6 +118,7 @@ static void make_gn(rnampnn_ctx* c, const std::string& prefix, int& scale, int& 
     scale = add_raw(c, prefix + ".scale", RN_D);
     shift = add_raw(c, prefix + ".shift", RN_D);
 }
+static Chain make_chain(rnampnn_ctx* c, const std::vector<Lin>& layers);
 static Bert make_bert(rnampnn_ctx* c, const std::string& prefix, int n_attn, int heads, int ffn_dim, int n_ffn) {
     Bert b;
     b.heads = heads;
@@ -133,8 +142,29 @@ static Bert make_bert(rnampnn_ctx* c, const std::string& prefix, int n_attn, int
         in = ffn_dim;
     }
     b.ffn.push_back(make_lin(c, prefix + ".ffn_layers." + std::to_string(3 * n_ffn), ffn_dim, RN_D, false));
+    b.chain = make_chain(c, b.ffn);
     return b;
 }
+// layers = [K0->H gelu] + NH x [H->H gelu] + [H->n_out plain]; fused when a kernel instance exists
+static Chain make_chain(rnampnn_ctx* c, const std::vector<Lin>& layers) {
+    Chain ch;
+    if (c->cfg.precision != RNAMPNN_PREC_BF16 || layers.size() < 2 || layers.size() > 4) return ch;
+    const Lin& first = layers.front();
+    const Lin& last = layers.back();
+    int H = first.out;
+    for (size_t i = 1; i + 1 < layers.size(); ++i)
+        if (layers[i].in != H || layers[i].out != H) return ch;
+    if (last.in != H || !first.gelu || last.gelu) return ch;
+    ch.K0 = first.in_pad; ch.H = H; ch.NH = (int)layers.size() - 2; ch.NOUT = (last.out + 31) / 32 * 32; ch.n_valid = last.out;
+    bool have = (ch.K0 == 128 && H == 512 && ch.NH == 2 && ch.NOUT == 128) || (ch.K0 == 32 && H == 512 && ch.NH == 2 && ch.NOUT == 128) ||
+                (ch.K0 == 256 && H == 512 && ch.NH == 0 && ch.NOUT == 32);
+    if (!have) return ch;
+    ch.ok = true;
+    ch.img = add_der(c, chain_image_bytes(ch.K0, ch.H, ch.NH, ch.NOUT));
+    ch.last_bias = add_der(c, ch.NOUT * sizeof(float));
+    return ch;
+}
+
 static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     Mlp2 m;
     m.depth = depth;
@@ -217,6 +247,7 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
         c->raw_ffn.push_back(make_lin(c, "raw_embedding.raw_ffn." + std::to_string(3 * g.num_raw_ffn_layers),
                                       g.num_raw_ffn_dim, RN_D, false));
         make_gn(c, "raw_embedding.graph_norm", c->rawffn_gn_scale, c->rawffn_gn_shift);
+        c->raw_chain = make_chain(c, c->raw_ffn);
     }
     {
         int in = 2 * RN_D;
@@ -226,6 +257,7 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
         }
         c->readout.push_back(make_lin(c, "readout.readout_layers." + std::to_string(3 * (g.num_readout_layers - 1)),
                                       in, 4, false));
+        c->readout_chain = make_chain(c, c->readout);
     }
     *out = c;
     return RNAMPNN_OK;
@@ -323,6 +355,21 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
     }
 }
 
+static void finalize_chain(rnampnn_ctx* c, const Chain& ch, const std::vector<Lin>& layers, hipStream_t s) {
+    if (!ch.ok) return;
+    bf16_t* dst = derp<bf16_t>(c, ch.img);
+    for (size_t i = 0; i < layers.size(); ++i) {
+        const Lin& l = layers[i];
+        bool last = i + 1 == layers.size();
+        int K = i == 0 ? ch.K0 : ch.H, N = last ? ch.NOUT : ch.H;
+        launch_build_chain_image(rawp(c, l.w), l.in, K, N, l.out, i == 0 ? 1 : 0, dst, s);
+        dst += (size_t)(N / 32) * (K / 16) * 512;
+    }
+    // derived arena was zeroed: bias beyond the real outputs stays 0
+    (void)hipMemcpyAsync(derp<float>(c, ch.last_bias), rawp(c, layers.back().b), layers.back().out * sizeof(float),
+                         hipMemcpyDeviceToDevice, s);
+}
+
 extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
     if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
     if (!h->raw_arena) return fail(RNAMPNN_ERR_WEIGHTS, "no weights have been set");
@@ -339,6 +386,10 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
     for (auto& m : h->mpnn) { finalize_mlp2(h, m.msg, false, s); finalize_mlp2(h, m.edge, true, s); }
     for (auto& l : h->raw_ffn) finalize_lin(h, l, s);
     for (auto& l : h->readout) finalize_lin(h, l, s);
+    finalize_chain(h, h->emb.chain, h->emb.ffn, s);
+    finalize_chain(h, h->post.chain, h->post.ffn, s);
+    finalize_chain(h, h->raw_chain, h->raw_ffn, s);
+    finalize_chain(h, h->readout_chain, h->readout, s);
     if (h->cfg.precision == RNAMPNN_PREC_BF16)
         launch_build_embed_image(rawp(h, h->edge_embed[0].w), rawp(h, h->edge_embed[1].w), rawp(h, h->edge_embed[1].b),
                                  derp<bf16_t>(h, h->edge_embed_img), derp<float>(h, h->edge_embed_b1p), s);
@@ -416,6 +467,18 @@ static void gemm(Run& r, const Lin& l, const float* X, int ldx, float* Y, int ld
                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
 }
 
+// fused FFN chain (fast path); returns false when the shape has no fused kernel
+static bool run_chain(Run& r, const Chain& ch, const std::vector<Lin>& layers, const float* X, int ldx, const float* X2,
+                      int ldx2, float* Y, int ldy) {
+    if (!r.fast || !ch.ok) return false;
+    rnampnn_ctx* c = r.c;
+    const float* bias[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (size_t i = 0; i + 1 < layers.size(); ++i) bias[i] = rawp(c, layers[i].b);
+    bias[layers.size() - 1] = derp<float>(c, ch.last_bias);
+    return launch_ffn_chain(r.ntot(), r.pk.Nmax, X, ldx, X2, ldx2, ch.K0, ch.H, ch.NH, ch.NOUT, derp<bf16_t>(c, ch.img),
+                            bias, Y, ldy, ch.n_valid, r.s) == 0;
+}
+
 // RNABert.forward on packed rows: x [N][128] -> out [N][128] (x is clobbered when attention layers exist)
 static int run_bert(Run& r, const Bert& b, float* x, float* out) {
     rnampnn_ctx* c = r.c;
@@ -425,6 +488,7 @@ static int run_bert(Run& r, const Bert& b, float* x, float* out) {
         gemm(r, a.out, r.w.n2, RN_D, r.w.s1, RN_D, x, RN_D);                          // x + out_proj(attn)
         launch_graph_norm_packed(r.pk, r.w.s1, nullptr, x, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s);
     }
+    if (run_chain(r, b.chain, b.ffn, x, RN_D, nullptr, 0, out, RN_D)) return RNAMPNN_OK;
     const float* cur = x;
     int ld = RN_D;
     float* bufs[2] = {r.w.s0, r.w.s1};
@@ -438,7 +502,8 @@ static int run_bert(Run& r, const Bert& b, float* x, float* out) {
     return RNAMPNN_OK;
 }
 
-static void run_ffn(Run& r, const std::vector<Lin>& ffn, const float* x, int ldx, float* out) {
+static void run_ffn(Run& r, const Chain& ch, const std::vector<Lin>& ffn, const float* x, int ldx, float* out) {
+    if (run_chain(r, ch, ffn, x, ldx, nullptr, 0, out, ffn.back().out)) return;
     const float* cur = x;
     int ld = ldx;
     float* bufs[2] = {r.w.s0, r.w.s1};
@@ -594,7 +659,7 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
     // ---- post fusion, raw embedding, readout (rnampnn.py:179-181)
     rc = run_bert(r, c->post, w.hA, w.n0);                     // h_post -> n0
     if (rc) return rc;
-    run_ffn(r, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
+    run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
     launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
     if (io->h_post) launch_unpack_nodes(r.pk, w.n0, RN_D, RN_D, io->h_post, s);
     if (io->raw_emb) launch_unpack_nodes(r.pk, w.n2, RN_D, RN_D, io->raw_emb, s);
@@ -602,7 +667,9 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
         launch_unpack_nodes_strided(r.pk, w.n0, RN_D, RN_D, io->embedding, 2 * RN_D, 0, s);
         launch_unpack_nodes_strided(r.pk, w.n2, RN_D, RN_D, io->embedding, 2 * RN_D, RN_D, s);
     }
-    if (io->logits) {
+    if (io->logits && run_chain(r, c->readout_chain, c->readout, w.n0, RN_D, w.n2, RN_D, w.logits_p, 4)) {
+        launch_unpack_nodes(r.pk, w.logits_p, 4, 4, io->logits, s);
+    } else if (io->logits) {
         const float* cur = nullptr;
         int ld = 0;
         float* bufs[2] = {w.s0, w.s1};
@@ -694,7 +761,7 @@ extern "C" int rnampnn_raw_ffn(rnampnn_handle h, const float* raw, const float* 
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(r.w.raw_p, 0, (size_t)r.pk.Nmax * RN_RAWP * sizeof(float), r.s));
     launch_pack_nodes(r.pk, raw, RN_RAW, r.w.raw_p, RN_RAWP, r.s);
-    run_ffn(r, h->raw_ffn, r.w.raw_p, RN_RAWP, r.w.n1);
+    run_ffn(r, h->raw_chain, h->raw_ffn, r.w.raw_p, RN_RAWP, r.w.n1);
     launch_graph_norm_packed(r.pk, r.w.n1, nullptr, r.w.n2, rawp(h, h->rawffn_gn_scale), rawp(h, h->rawffn_gn_shift),
                              T_norm > 0 ? T_norm : T, r.s);
     launch_unpack_nodes(r.pk, r.w.n2, RN_D, RN_D, y, r.s);

@@ -28,3 +28,11 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
                       float* agg, float* msg_out, hipStream_t s);   // agg [N][128]: masked mean of the messages (no residual)
+
+// fused FFN chain  X -> Linear(K0,H)+GELU -> NH x [Linear(H,H)+GELU] -> Linear(H,NOUT)  (see kernels_bf16.hip)
+void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s);
+static inline size_t chain_image_bytes(int K0, int H, int NH, int NOUT) {
+    return ((size_t)(H / 32) * (K0 / 16) + (size_t)NH * (H / 32) * (H / 16) + (size_t)(NOUT / 32) * (H / 16)) * 1024;
+}
+int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const float* X2, int ldx2, int K0, int H, int NH,
+                     int NOUT, const bf16_t* img, const float* const* bias, float* Y, int ldy, int n_valid, hipStream_t s);

@@ -718,3 +718,138 @@ void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1
     hipLaunchKernelGGL(k_gemm_bf16, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, W, bias, N, act, res, ldres, Y, ldy,
                        Yb, ldyb, col_split);
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused node-level FFN chain on MFMA (functional.py:119-127,170 / 179-187,200 / 62-74,86):
+//   X (f32 rows, K0 wide) -> Linear(K0,H)+GELU -> NH x [Linear(H,H)+GELU] -> Linear(H,NOUT)
+// evaluated transposed like the edge MLPs (rows of the batch on the MFMA columns = lanes, channels
+// on the accumulator registers), so the hidden activations of a 32-row block never leave the
+// registers of their wave: 128 VGPRs hold 512 bf16 channels as ready-made B fragments.  A
+// 256-thread workgroup (4 waves x 32 rows, one wave per SIMD, whole 512-register file) streams
+// the weights ONCE per 128 rows: fragment images (1 KiB = one MFMA A fragment, consumption order)
+// are copied global -> registers -> LDS double buffer, one chunk = one 32-channel output block.
+struct ChainW {
+    const bf16_t* img;        // all layers' fragment chunks, consumption order
+    const float* bias[5];     // per layer, natural channel order (last layer padded to NOUT)
+};
+
+struct ChunkRegs { u32x4 v[8]; };       // one chunk of up to 32 fragments (32 KiB / 256 threads) in flight
+
+template <int NFR>
+__device__ __forceinline__ void chunk_load(ChunkRegs& c, const u32x4* __restrict__ src, int tid) {
+#pragma unroll
+    for (int i = 0; i < (NFR * 64 + 255) / 256; ++i) c.v[i] = src[i * 256 + tid];
+}
+template <int NFR>
+__device__ __forceinline__ void chunk_store(const ChunkRegs& c, u32x4* dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < (NFR * 64 + 255) / 256; ++i) dst[i * 256 + tid] = c.v[i];
+}
+
+// one Linear of the chain: NOB output blocks of NKS k-steps; in[] are the B fragments of its input.
+// On entry `cr` holds the layer's first chunk; each step parks its chunk in the LDS double buffer,
+// issues the loads of the NEXT chunk (NEXT_NKS fragments when it belongs to the next layer) and then
+// runs its MFMAs, so the weight stream stays one chunk ahead of the matrix pipe.
+// GELU + repack into out[] (hidden layers) or f32 store (last layer).
+template <int NKS, int NOB, int NEXT_NKS, bool LAST>
+__device__ __forceinline__ void chain_layer(ChunkRegs& cr, const u32x4* __restrict__& wsrc, u32x4* wbuf, int& parity, int tid,
+                                            int lane, int h, const u32x4 (&in)[32], u32x4 (&out)[32],
+                                            const float* __restrict__ bias, float* __restrict__ yrow, int n_valid, bool row_ok) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        u32x4* buf = wbuf + parity * (32 * 64);
+        chunk_store<NKS>(cr, buf, tid);
+        __syncthreads();
+        parity ^= 1;
+        wsrc += NKS * 64;
+        if (ob + 1 < NOB) chunk_load<NKS>(cr, wsrc, tid);
+        else if (NEXT_NKS > 0) chunk_load<(NEXT_NKS > 0 ? NEXT_NKS : 1)>(cr, wsrc, tid);
+        f32x16 acc = init_vec16(bias + 32 * ob + 16 * h);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) acc = mfma32(buf[ks * 64 + lane], in[ks], acc);
+        if (!LAST) {
+            gelu_pack(acc, out[2 * ob], out[2 * ob + 1]);
+        } else if (row_ok) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c0 = 32 * ob + 16 * h + 4 * v;
+                if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K0, int H, int NH, int NOUT>
+__global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx,
+        const float* __restrict__ X2, int ldx2, ChainW w, float* __restrict__ Y, int ldy, int n_valid) {
+    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2 * 32 * 64];     // 2 x 32 KiB
+    const int ntot = *ntot_p;
+    const int row_blk = blockIdx.x * 128;
+    if (row_blk >= ntot) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int row = row_blk + 32 * wave + r;
+    const bool row_ok = row < ntot;
+    u32x4 a[32], b[32];
+    // input rows -> B fragments (natural k order): X for k < 128 (or all of K0), X2 beyond
+#pragma unroll
+    for (int s = 0; s < K0 / 16; ++s) {
+        const int kk = 16 * s + 8 * h;
+        const float* src = (K0 > 128 && kk >= 128) ? X2 + (size_t)row * ldx2 + (kk - 128) : X + (size_t)row * ldx + kk;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (row_ok) { v0 = *reinterpret_cast<const f32x4*>(src); v1 = *reinterpret_cast<const f32x4*>(src + 4); }
+        a[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+    }
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(w.img);
+    int parity = 0;
+    float* yrow = Y + (size_t)row * ldy;
+    ChunkRegs cr;
+    chunk_load<K0 / 16>(cr, wsrc, tid);
+    constexpr int HK = H / 16, HB = H / 32, OB = NOUT / 32;
+    chain_layer<K0 / 16, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[0], yrow, n_valid, row_ok);
+    if (NH == 0) {
+        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
+    } else if (NH == 1) {
+        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
+        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[2], yrow, n_valid, row_ok);
+    } else {
+        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
+        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[2], yrow, n_valid, row_ok);
+        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[3], yrow, n_valid, row_ok);
+    }
+}
+
+// chain weight image: layer with K inputs, N outputs (rows >= n_real are zero): chunks [ob][ks][lane][8];
+// first layer: k natural (16 ks + 8h + j); later layers: ks = 2mb + s' <-> channel 32mb + 16h + 8s' + j
+__global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, int K, int N, int n_real, int first,
+                                    bf16_t* __restrict__ dst) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int nks = K / 16;
+    if (id >= (N / 32) * nks * 64 * 8) return;
+    int j = id & 7, lane = (id >> 3) & 63, f = id >> 9;
+    int ob = f / nks, ks = f % nks, r = lane & 31, h = lane >> 5;
+    int row = ch_nat(ob, r);
+    int col = first ? 16 * ks + 8 * h + j : 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j;
+    dst[id] = (row < n_real && col < K_real) ? f2bf(wraw[(size_t)row * K_real + col]) : (bf16_t)0;
+}
+void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s) {
+    int total = (N / 32) * (K / 16) * 512;
+    hipLaunchKernelGGL(k_build_chain_image, dim3((total + 255) / 256), dim3(256), 0, s, wraw, K_real, K, N, n_real, first, dst);
+}
+
+// returns 0 when the (K0, H, NH, NOUT) shape has a fused kernel, 1 otherwise (caller falls back to GEMMs)
+int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const float* X2, int ldx2, int K0, int H, int NH,
+                     int NOUT, const bf16_t* img, const float* const* bias, float* Y, int ldy, int n_valid, hipStream_t s) {
+    ChainW w;
+    w.img = img;
+    for (int i = 0; i < 5; ++i) w.bias[i] = i < NH + 2 ? bias[i] : nullptr;
+    dim3 grid((mmax + 127) / 128);
+#define RN_CHAIN(k0, hh, nh, no) \
+    if (K0 == k0 && H == hh && NH == nh && NOUT == no) { \
+        hipLaunchKernelGGL((k_ffn_chain<k0, hh, nh, no>), grid, dim3(256), 0, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; }
+    RN_CHAIN(128, 512, 2, 128)
+    RN_CHAIN(32, 512, 2, 128)
+    RN_CHAIN(256, 512, 0, 32)
+#undef RN_CHAIN
+    return 1;
+}
