@@ -57,7 +57,8 @@ struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     int w[2], b[2];           // RawT indices
     size_t pq_t, pq_b;        // derived f32: [128][256] K-major (P | Q parts of Linear 0), bias [b1 | 0]
     size_t wc_t, w2_t;        // derived f32: e-part of Linear 0 and Linear 1, K-major
-    size_t pq_wb;             // derived bf16 [256][128]  (fast path node GEMM)
+    size_t pq_wb;             // derived bf16 [256][128]  (fast path node GEMM, stage API)
+    size_t pq_img;            // derived bf16 [P | Q] fragment image for the fused node-update kernel
     size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
     size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
 };
@@ -179,6 +180,7 @@ static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     m.wc_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
     m.w2_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
     m.pq_wb = add_der(c, (size_t)256 * RN_D * sizeof(bf16_t));
+    m.pq_img = add_der(c, (size_t)64 * 1024);
     m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
     m.b2p = add_der(c, RN_D * sizeof(float));
     return m;
@@ -350,6 +352,7 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
         // node GEMM weights [P rows | Q rows] = W0[:, 0:128] and W0[:, 128:256], bf16 [256][128]
         launch_convert_rows_bf16(w0, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb), s);
         launch_convert_rows_bf16(w0 + RN_D, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb) + RN_D * RN_D, s);
+        launch_build_pq_image(w0, derp<bf16_t>(c, m.pq_img), s);
         launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
                                derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
     }
@@ -402,6 +405,7 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
 struct Ws {                       // workspace carve (all offsets 256-byte aligned)
     int *len, *cu, *node_b, *nbr;
     float *geom, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
+    float* coef;                  // fast path: per-RNA GraphNorm affine coefficients [B][256]
     bf16_t *q_e, *q_m;            // fast path: bf16 Q tables [(Nmax+1)][128]; pq_* then hold P as [(Nmax+1)][128] f32
     void* e;                      // f32 or bf16 [Nmax*k][128]
     float* big;                   // [Nmax*k][128] f32 scratch for the stage API / edge taps
@@ -425,6 +429,7 @@ static size_t carve(const rnampnn_ctx* c, int B, int T, char* base, Ws* w) {
     r.hB = (float*)take((Nmax + 1) * RN_D * sizeof(float));
     r.pq_e = (float*)take((Nmax + 1) * 256 * sizeof(float));
     r.pq_m = (float*)take((Nmax + 1) * 256 * sizeof(float));
+    r.coef = (float*)take((size_t)B * 256 * sizeof(float));
     r.q_e = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
     r.q_m = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
     r.s0 = (float*)take(Nmax * F * sizeof(float));
@@ -630,23 +635,42 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
     gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
     rc = run_bert(r, c->emb, w.n0, w.n1);
     if (rc) return rc;
-    launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
+    const bool fused_first = r.fast && io->stop_after != 1;
+    if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass
+        launch_node_update(r.pk, w.n1, nullptr, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, w.coef, w.hA, 1,
+                           derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_b), w.pq_m, w.q_m,
+                           nullptr, nullptr, nullptr, nullptr, s);
+    else
+        launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
     if (io->h0) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h0, s);
     if (io->e0) unpack_e(r, io->e0);
     if (io->stop_after == 1) { HIP_TRY(hipGetLastError()); return RNAMPNN_OK; }
 
     // ---- L x ResMPNN.forward (mpnn.py:283-294), edge update of layer l fused with the message of l+1
-    node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m, w.q_m);
+    if (!fused_first) node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m, w.q_m);
     bool edge_pending = false;                                 // layer l-1's edge update not yet applied
     for (int l = 0; l < L; ++l) {
         mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr);
-        // f32 kernels write h + agg; the bf16 kernel writes agg and the norm kernel takes the residual
-        launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, rawp(c, c->mpnn[l].gn_scale),
-                                 rawp(c, c->mpnn[l].gn_shift), t_norm, s);
         bool tap_e = io->tap_layer == l + 1 && io->e_layer;
         edge_pending = l + 1 < L;                              // layer L's edge update is dead work
-        if (edge_pending || tap_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e, w.q_e);
-        if (l + 1 < L) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m, w.q_m);
+        const bool need_e = edge_pending || tap_e, need_m = l + 1 < L;
+        const float* gsc = rawp(c, c->mpnn[l].gn_scale);
+        const float* gsh = rawp(c, c->mpnn[l].gn_shift);
+        if (r.fast && (need_e || need_m)) {
+            // the bf16 kernel wrote agg; residual + GraphNorm + both [P | Q] projections in one kernel
+            const Mlp2* j0 = need_e ? &c->mpnn[l].edge : &c->mpnn[l + 1].msg;
+            const Mlp2* j1 = (need_e && need_m) ? &c->mpnn[l + 1].msg : nullptr;
+            float* p0 = need_e ? w.pq_e : w.pq_m;
+            bf16_t* q0 = need_e ? w.q_e : w.q_m;
+            launch_node_update(r.pk, w.hB, w.hA, gsc, gsh, t_norm, w.coef, w.hA, j1 ? 2 : 1, derp<bf16_t>(c, j0->pq_img),
+                               derp<float>(c, j0->pq_b), p0, q0, j1 ? derp<bf16_t>(c, j1->pq_img) : nullptr,
+                               j1 ? derp<float>(c, j1->pq_b) : nullptr, j1 ? w.pq_m : nullptr, j1 ? w.q_m : nullptr, s);
+        } else {
+            // f32 kernels write h + agg; the bf16 kernel writes agg and the norm kernel takes the residual
+            launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, gsc, gsh, t_norm, s);
+            if (need_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e, w.q_e);
+            if (need_m) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m, w.q_m);
+        }
         if (io->tap_layer == l + 1) {
             if (io->h_layer) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h_layer, s);
             if (tap_e) {

@@ -36,3 +36,10 @@ static inline size_t chain_image_bytes(int K0, int H, int NH, int NOUT) {
 }
 int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const float* X2, int ldx2, int K0, int H, int NH,
                      int NOUT, const bf16_t* img, const float* const* bias, float* Y, int ldy, int n_valid, hipStream_t s);
+
+// fused node update: h' = GraphNorm(x + add) (scale == null: h' = x + add, no norm), then [P | Q] projections
+// of up to two first Linears (P f32 [N][128], Q bf16 [N][128]); coef = scratch [B][256]
+void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s);
+void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
+                        float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
+                        const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s);

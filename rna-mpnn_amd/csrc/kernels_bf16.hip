@@ -853,3 +853,160 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
 #undef RN_CHAIN
     return 1;
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused node update between two ResMPNN steps (mpnn.py:222-225, 289; functional.py:33-46):
+//   x = h + agg  ->  GraphNormalization  ->  h'  ->  [P | Q] = h' . [Wa | Wb]^T (+ b1) for up to two
+// first Linears (edge MLP of this layer, message MLP of the next).  k_gn_coef reduces the per-RNA
+// statistics to an affine map y = a x + b per (RNA, channel); k_node_update applies it to 32-row
+// blocks held as B fragments, writes h' (f32) and runs the projections on MFMA with the
+// [P | Q] weight images resident in LDS (64 KiB per job): P -> f32, Q -> bf16 (gather tables of
+// the edge kernel).
+__global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ coef) {
+    __shared__ float4 rs[8][8], rq[8][8];
+    const int b = blockIdx.x, cg = blockIdx.y;                 // RNA, group of 32 channels
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const size_t base = (size_t)pk.cu[b] * RN_D + 32 * cg;
+    const int cq = threadIdx.x & 7, g = threadIdx.x >> 3;      // channel quad, row group (32)
+    const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
+    const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    for (int r = g; r < n; r += 32) {
+        float4 v = xb[(size_t)r * 32];
+        if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+    }
+    // reduce the 32 row groups: 4 lanes-of-8 per wave via shuffles, then 4 waves via LDS
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64); q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) { rs[wave][lane] = s; rq[wave][lane] = q; }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float4 S = rs[0][cq], Q = rq[0][cq];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            float4 u = rs[w][cq], v = rq[w][cq];
+            S.x += u.x; S.y += u.y; S.z += u.z; S.w += u.w; Q.x += v.x; Q.y += v.y; Q.z += v.z; Q.w += v.w;
+        }
+        const float fn = (float)n, pad = (float)(t_tot - 2 * n);
+        const float4 sc = reinterpret_cast<const float4*>(scale + 32 * cg)[cq], sh = reinterpret_cast<const float4*>(shift + 32 * cg)[cq];
+        float mean[4] = {S.x / fn, S.y / fn, S.z / fn, S.w / fn};
+        float sq[4] = {Q.x, Q.y, Q.z, Q.w}, scl[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
+        float a[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // var = [sum (x-mu)^2 + (T-n) mu^2] / n = [sum x^2 + (T - 2n) mu^2] / n
+            float var = fmaxf((sq[i] + pad * mean[i] * mean[i]) / fn, 0.f);
+            a[i] = scl[i] / sqrtf(var + kSEPS);
+            bb[i] = shf[i] - mean[i] * a[i];
+        }
+        float* cb = coef + (size_t)b * 256 + 32 * cg + 4 * cq;
+        *reinterpret_cast<float4*>(cb) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(cb + 128) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+    }
+}
+
+struct PqJob { const bf16_t* img; const float* bias; float* p; bf16_t* q; };   // img: [8 ob][8 ks][64][8]; ob<4 -> P rows, >=4 -> Q rows
+
+template <int NJOBS>
+__global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        const float* __restrict__ coef, float* __restrict__ h_out, PqJob j0, PqJob j1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* img = reinterpret_cast<u32x4*>(smem);
+    const int ntot = pk.cu[pk.B];
+    const int row_blk = blockIdx.x * 128;
+    if (row_blk >= ntot) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < 4096; i += 256) img[i] = reinterpret_cast<const u32x4*>(j0.img)[i];
+    if (NJOBS > 1) for (int i = tid; i < 4096; i += 256) img[4096 + i] = reinterpret_cast<const u32x4*>(j1.img)[i];
+    const int row = row_blk + 32 * wave + r;
+    const bool ok = row < ntot;
+    const int rr = ok ? row : 0;
+    const float* cf = coef + (size_t)pk.node_b[rr] * 256;
+    u32x4 xf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c0 = 16 * s + 8 * h;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0), v1 = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0 + 4);
+        if (add) {
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0), a1 = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0 + 4);
+            v0 += a0; v1 += a1;
+        }
+        if (coef) {
+            f32x4 ca0 = *reinterpret_cast<const f32x4*>(cf + c0), ca1 = *reinterpret_cast<const f32x4*>(cf + c0 + 4);
+            f32x4 cb0 = *reinterpret_cast<const f32x4*>(cf + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4);
+            v0 = v0 * ca0 + cb0; v1 = v1 * ca1 + cb1;
+        }
+        if (ok && h_out) {
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0) = v0;
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = v1;
+        }
+        xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < NJOBS; ++jb) {
+        const PqJob& jbq = jb == 0 ? j0 : j1;
+        const u32x4* im = img + jb * 4096;
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+            f32x16 acc;
+            if (ob < 4) acc = init_vec16(jbq.bias + 32 * ob + 16 * h);
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
+            if (ok) {
+                if (ob < 4) {
+                    float* dst = jbq.p + (size_t)row * RN_D + 32 * ob + 16 * h;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        *reinterpret_cast<f32x4*>(dst + 4 * v) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+                } else {
+                    u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + (size_t)row * RN_D + 32 * (ob - 4) + 16 * h);
+                    dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
+                    dst[1] = u32x4{pack2(acc[8], acc[9]), pack2(acc[10], acc[11]), pack2(acc[12], acc[13]), pack2(acc[14], acc[15])};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256]
+__global__ void k_build_pq_image(const float* __restrict__ w0, bf16_t* __restrict__ dst) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 8 * 8 * 64 * 8) return;
+    int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, ob = f >> 3, ks = f & 7, r = lane & 31, h = lane >> 5;
+    int row = ch_nat(ob & 3, r), col = (ob < 4 ? 0 : 128) + 16 * ks + 8 * h + j;
+    dst[id] = f2bf(w0[(size_t)row * 384 + col]);
+}
+void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_pq_image, dim3(8 * 8 * 64 * 8 / 256), dim3(256), 0, s, w0, dst);
+}
+
+void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
+                        float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
+                        const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s) {
+    if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
+    PqJob j0{img0, bias0, p0, q0}, j1{img1, bias1, p1, q1};
+    dim3 grid((pk.Nmax + 127) / 128);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)k_node_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)k_node_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        done = true;
+    }
+    const float* cf = scale ? coef : nullptr;
+    if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536, s, pk, x, add, cf, h_out, j0, j1);
+    else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072, s, pk, x, add, cf, h_out, j0, j1);
+}
