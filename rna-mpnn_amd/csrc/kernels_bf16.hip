@@ -286,8 +286,14 @@ struct NodeTabs {             // per-residue parts of the first Linears (node GE
     unsigned long long* dbg;  // RN_STAMPS diagnostic buffer (null otherwise)
 };
 
+#ifndef RN_MPNN_WAVES
+#define RN_MPNN_WAVES 12          // waves per workgroup (one workgroup per CU): 12 = 3 per SIMD (<= 168 VGPRs)
+#endif
+#ifndef RN_MPNN_PREFETCH
+#define RN_MPNN_PREFETCH 0        // 1: next block's e fragments are loaded one block ahead (+32 VGPRs)
+#endif
 template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
-__global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
+__global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
     // LDS: [img_e 64 KiB][img_m 64 KiB][b2 of edge MLP 512 B][b2 of message MLP 512 B][per wave: P_e | P_m rows, 1 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -297,8 +303,9 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
     float* lds_b2m = lds_b2e + 128;
     const int tid = threadIdx.x;
     float* lds_p = lds_b2m + 128 + (tid >> 6) * 256;
-    if (DO_EDGE) for (int i = tid; i < 4096; i += 512) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
-    if (DO_MSG) for (int i = tid; i < 4096; i += 512) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
+    constexpr int NW = RN_MPNN_WAVES;
+    if (DO_EDGE) for (int i = tid; i < 4096; i += NW * 64) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
+    if (DO_MSG) for (int i = tid; i < 4096; i += NW * 64) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
     if (tid < 128) { lds_b2e[tid] = DO_EDGE ? we.b2p[tid] : 0.f; lds_b2m[tid] = DO_MSG ? wm.b2p[tid] : 0.f; }
     __syncthreads();
 
@@ -307,10 +314,10 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
     const int nblocks = (ntot + npb - 1) / npb;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int zero_row = pk.Nmax;
-    const int stride = gridDim.x * 8;
+    const int stride = gridDim.x * NW;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    int blk = blockIdx.x * 8 + wave;
+    int blk = blockIdx.x * NW + wave;
     if (blk >= nblocks) return;
     BlockLane bl = block_lane(blk, npb, k, ntot, r, nbr);
     u32x4 ef[8];
@@ -354,16 +361,20 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
             mlp_first(img_e, lane, ef, SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : lds_p + 16 * h, qe, hb);
         }
         STAMP(t2);
+#if RN_MPNN_PREFETCH
         // Q_m gather and the next block's e fragments: in flight during the following Linear(s)
         if (DO_MSG) {
             const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D + 16 * h);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) { qm[2 * mb] = qp[4 * mb]; qm[2 * mb + 1] = qp[4 * mb + 1]; }
         }
+#endif
         {
+#if RN_MPNN_PREFETCH
             const u32x4* erp = efrag_ptr(e, has_next ? nblk : blk, lane);
 #pragma unroll
             for (int s = 0; s < 8; ++s) efn[s] = (has_next && bn.ok) ? erp[64 * s] : zero4;
+#endif
             if (!SMALLK && has_next) {
                 if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nblk * RN_D + 2 * lane);
                 if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nblk * RN_D + 2 * lane);
@@ -393,6 +404,13 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
             }
         }
         STAMP(t4);
+#if !RN_MPNN_PREFETCH
+        if (DO_MSG) {       // 3 waves per SIMD cover this gather; issuing it here keeps the kernel within 168 VGPRs
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D + 16 * h);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { qm[2 * mb] = qp[4 * mb]; qm[2 * mb + 1] = qp[4 * mb + 1]; }
+        }
+#endif
         if (DO_MSG) {
             mlp_first(img_m, lane, ef, SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : lds_p + 128 + 16 * h, qm, hb);
             STAMP(t5);
@@ -442,8 +460,16 @@ __global__ void __launch_bounds__(512, 2) k_mpnn_bf16(PackInfo pk, int k, const 
         if (!has_next) break;
         blk = nblk;
         bl = bn;
+#if RN_MPNN_PREFETCH
 #pragma unroll
         for (int s = 0; s < 8; ++s) ef[s] = efn[s];
+#else
+        {
+            const u32x4* erp = efrag_ptr(e, blk, lane);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ef[s] = bl.ok ? erp[64 * s] : zero4;
+        }
+#endif
     }
 #ifdef RN_STAMPS
     if (tab.dbg && lane == 0)
@@ -467,10 +493,10 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
                       float* agg, float* msg_out, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
-    int grid = (max_blocks + 7) / 8;
+    int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
-    size_t lds = 131072 + 1024 + 8 * 1024;
+    size_t lds = 131072 + 1024 + RN_MPNN_WAVES * 1024;
     NodeTabs tab{p_e, q_e, p_m, q_m, nullptr};
 #ifdef RN_STAMPS
     static unsigned long long* dbg = nullptr;
@@ -483,10 +509,10 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     do {                                                                                                       \
         static bool done = false;                                                                              \
         if (!done) {                                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024 + 8192); \
+            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024 + RN_MPNN_WAVES * 1024); \
             done = true;                                                                                       \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(512), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
+        hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(RN_MPNN_WAVES * 64), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
     } while (0)
     if (do_edge && do_msg) { if (smallk) RN_LAUNCH(true, true, true, false); else RN_LAUNCH(true, true, false, false); }
     else if (do_edge)      { if (smallk) RN_LAUNCH(true, false, true, false); else RN_LAUNCH(true, false, false, false); }

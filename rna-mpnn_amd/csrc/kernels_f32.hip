@@ -180,17 +180,22 @@ void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float*
 // and are never real neighbours.  Slot n-1 (when n-1 < k): the reference keeps one extra edge
 // to a PADDED residue iff T > n -> the phantom neighbour (index n in the
 // API tensor, row Nmax + b in the packed index); all later slots are -1.
+// G = lanes cooperating on one row (64: one wave per row, any T that fits LDS; 16: four rows per
+// wave, 4x the rows in flight - the extraction loop is a chain of dependent cross-lane reductions,
+// so throughput comes from rows in flight, not from lanes per row).
+template <int G>
 __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, PackInfo pk, int k, int rows_per_block,
                                               int* __restrict__ nbr, int64_t* __restrict__ eidx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int GROUPS = 256 / G;
     int b = blockIdx.x;
     int n = pk.len[b];
     int T = pk.T;
     int row0 = blockIdx.y * rows_per_block;
     if (row0 >= T) return;
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int gl = threadIdx.x % G, grp = threadIdx.x / G;
     float* cen = sm;                       // [T][3]
-    float* drow = sm + 3 * T + w * T;      // per-wave distance row
+    float* drow = sm + 3 * T + grp * T;    // per-group distance row
     if (row0 < n) {
         for (int j = threadIdx.x; j < n; j += 256) {
             const float* c = coords + ((size_t)b * T + j) * 21;
@@ -202,56 +207,76 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, P
     }
     __syncthreads();
     int base = pk.cu[b];
-    for (int i = row0 + w; i < min(T, row0 + rows_per_block); i += 4) {
-        if (i >= n) {                                           // padded row: all -1 (feature.py:253-254)
-            if (eidx) for (int s = lane; s < k; s += 64) eidx[((size_t)b * T + i) * k + s] = -1;
-            continue;
+    const int row_end = min(T, row0 + rows_per_block);
+    for (int i0 = row0; i0 < row_end; i0 += GROUPS) {
+        const int i = i0 + grp;
+        const bool row_live = i < row_end;          // groups of one wave stay in step (shuffles below)
+        const bool real = row_live && i < n;
+        if (row_live && !real) {                     // padded row: all -1 (feature.py:253-254)
+            if (eidx) for (int s = gl; s < k; s += G) eidx[((size_t)b * T + i) * k + s] = -1;
         }
-        float cx = cen[i * 3], cy = cen[i * 3 + 1], cz = cen[i * 3 + 2];
-        for (int j = lane; j < n; j += 64) {
-            float dx = __fsub_rn(cen[j * 3], cx), dy = __fsub_rn(cen[j * 3 + 1], cy), dz = __fsub_rn(cen[j * 3 + 2], cz);
-            float ss = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            drow[j] = (j == i) ? 3.0e38f : sqrtf(__fadd_rn(ss, kSEPS));
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (real) { cx = cen[i * 3]; cy = cen[i * 3 + 1]; cz = cen[i * 3 + 2]; }
+        if (real) {
+            for (int j = gl; j < n; j += G) {
+                float dx = __fsub_rn(cen[j * 3], cx), dy = __fsub_rn(cen[j * 3 + 1], cy), dz = __fsub_rn(cen[j * 3 + 2], cz);
+                float ss = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                drow[j] = (j == i) ? 3.0e38f : sqrtf(__fadd_rn(ss, kSEPS));
+            }
         }
-        // (wave-private LDS row: same-wave accesses are program ordered)
-        int nreal = min(k, n - 1);
-        unsigned long long prev = 0ull;                         // keys are > 0 (distance >= 1e-3)
-        size_t pbase = (size_t)(base + i) * k;
-        size_t obase = ((size_t)b * T + i) * k;
-        for (int s = 0; s < nreal; ++s) {
+        // (group-private LDS row, written and read by the same lanes: program ordered)
+        const int nreal = real ? min(k, n - 1) : 0;
+        int nmax = nreal;                            // wave-uniform trip count
+#pragma unroll
+        for (int o = G; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        unsigned long long prev = 0ull;              // keys are > 0 (distance >= 1e-3)
+        const size_t pbase = (size_t)(base + i) * k;
+        const size_t obase = ((size_t)b * T + i) * k;
+        for (int s = 0; s < nmax; ++s) {
             unsigned long long best = ~0ull;
-            for (int j = lane; j < n; j += 64) {
-                unsigned long long key = ((unsigned long long)__float_as_uint(drow[j]) << 32) | (unsigned)j;
-                if (key > prev && key < best) best = key;
+            if (s < nreal) {
+                for (int j = gl; j < n; j += G) {
+                    unsigned long long key = ((unsigned long long)__float_as_uint(drow[j]) << 32) | (unsigned)j;
+                    if (key > prev && key < best) best = key;
+                }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = G / 2; o > 0; o >>= 1) {
                 unsigned long long other = __shfl_xor(best, o, 64);
                 best = other < best ? other : best;
             }
             prev = best;
-            if (lane == 0) {
+            if (gl == 0 && s < nreal) {
                 int j = (int)(best & 0xffffffffu);
                 nbr[pbase + s] = base + j;
                 if (eidx) eidx[obase + s] = j;
             }
         }
-        for (int s = nreal + lane; s < k; s += 64) {
-            bool phantom = (s == n - 1) && (n < T);
-            nbr[pbase + s] = phantom ? pk.Nmax + b : -1;
-            if (eidx) eidx[obase + s] = phantom ? n : -1;
+        if (real) {
+            for (int s = nreal + gl; s < k; s += G) {
+                bool phantom = (s == n - 1) && (n < T);
+                nbr[pbase + s] = phantom ? pk.Nmax + b : -1;
+                if (eidx) eidx[obase + s] = phantom ? n : -1;
+            }
         }
     }
 }
 
 int launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t* eidx, hipStream_t s) {
+    const size_t lds16 = (size_t)(3 + 16) * pk.T * sizeof(float);
+    if (lds16 <= 48 * 1024) {                        // four rows per wave
+        int rpb = 32;
+        dim3 grid(pk.B, (pk.T + rpb - 1) / rpb);
+        hipLaunchKernelGGL(k_knn<16>, grid, dim3(256), lds16, s, coords, pk, k, rpb, nbr, eidx);
+        return 0;
+    }
     size_t lds = (size_t)(3 + 4) * pk.T * sizeof(float);
     if (lds > 160 * 1024 - 256) return 1;                       // T too long for the LDS-resident row
     if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void*)k_knn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int rpb = pk.T <= 512 ? 16 : 64;
     dim3 grid(pk.B, (pk.T + rpb - 1) / rpb);
-    hipLaunchKernelGGL(k_knn, grid, dim3(256), lds, s, coords, pk, k, rpb, nbr, eidx);
+    hipLaunchKernelGGL(k_knn<64>, grid, dim3(256), lds, s, coords, pk, k, rpb, nbr, eidx);
     return 0;
 }
 
