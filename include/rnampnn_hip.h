@@ -147,6 +147,11 @@ int rnampnn_argmax_recovery(const float* logits, const float* mask, const int32_
  * Counter-based RNG: draw = f(seed, sample, b, t) - reproducible and graph-replay safe. */
 int rnampnn_sample(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
                    int32_t n_samples, uint64_t seed, int8_t* out, void* stream);
+/* Same, with the seed read from DEVICE memory at kernel time: a hipGraph that captured this launch
+ * draws fresh samples on every replay once the caller has updated *seed_device (BASELINE config 5:
+ * "hipGraph-captured decode step"). */
+int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
+                            int32_t n_samples, const uint64_t* seed_device, int8_t* out, void* stream);
 
 /* -- measurement ------------------------------------------------------------------------- */
 /* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when

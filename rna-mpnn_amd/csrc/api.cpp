@@ -829,7 +829,17 @@ extern "C" int rnampnn_sample(const float* logits, const float* mask, int32_t B,
     if (!logits || !mask || !out || B <= 0 || T <= 0 || n_samples <= 0)
         return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_sample: bad argument");
     if (!(temperature > 0.f)) return fail(RNAMPNN_ERR_BAD_ARG, "temperature must be > 0");
-    launch_sample(logits, mask, B, T, temperature, n_samples, seed, out, (hipStream_t)stream);
+    launch_sample(logits, mask, B, T, temperature, n_samples, seed, nullptr, out, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
+                                       int32_t n_samples, const uint64_t* seed_device, int8_t* out, void* stream) {
+    if (!logits || !mask || !out || !seed_device || B <= 0 || T <= 0 || n_samples <= 0)
+        return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_sample_dev_seed: bad argument");
+    if (!(temperature > 0.f)) return fail(RNAMPNN_ERR_BAD_ARG, "temperature must be > 0");
+    launch_sample(logits, mask, B, T, temperature, n_samples, 0, seed_device, out, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return RNAMPNN_OK;
 }

@@ -873,7 +873,9 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     return x;
 }
 __global__ void k_sample(const float* __restrict__ logits, const float* __restrict__ mask, int B, int T, float inv_temp,
-                         int n_samples, unsigned long long seed, int8_t* __restrict__ out) {
+                         int n_samples, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                         int8_t* __restrict__ out) {
+    if (seed_dev) seed = *seed_dev;
     size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t per = (size_t)B * T;
     if (id >= per * n_samples) return;
@@ -891,8 +893,9 @@ __global__ void k_sample(const float* __restrict__ logits, const float* __restri
     out[id] = (int8_t)a;
 }
 void launch_sample(const float* logits, const float* mask, int B, int T, float temperature, int n_samples,
-                   uint64_t seed, int8_t* out, hipStream_t s) {
+                   uint64_t seed, const uint64_t* seed_dev, int8_t* out, hipStream_t s) {
     size_t total = (size_t)B * T * n_samples;
     hipLaunchKernelGGL(k_sample, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits, mask, B, T,
-                       1.0f / temperature, n_samples, (unsigned long long)seed, out);
+                       1.0f / temperature, n_samples, (unsigned long long)seed,
+                       reinterpret_cast<const unsigned long long*>(seed_dev), out);
 }

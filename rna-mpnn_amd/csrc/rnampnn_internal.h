@@ -61,4 +61,4 @@ void launch_transpose(const float* src, int ld_src, int rows, int cols, float* d
 void launch_argmax_recovery(const float* logits, const float* mask, const int32_t* labels, int B, int T,
                             int8_t* pred, int32_t* correct, int32_t* valid, hipStream_t s);
 void launch_sample(const float* logits, const float* mask, int B, int T, float temperature, int n_samples,
-                   uint64_t seed, int8_t* out, hipStream_t s);
+                   uint64_t seed, const uint64_t* seed_dev, int8_t* out, hipStream_t s);

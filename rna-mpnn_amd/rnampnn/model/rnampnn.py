@@ -171,3 +171,48 @@ def sample_from_logits(logits: torch.Tensor, mask: torch.Tensor, temperature: fl
         _native.check(_native.lib().rnampnn_sample(_ptr(lg), _ptr(m), B, T, float(temperature), int(n_samples),
                                                    C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(out), _stream(device)))
     return out
+
+
+class CapturedSampler:
+    """hipGraph-captured decode step (BASELINE config 5): ONE graph holding the whole forward and the
+    sampling kernel for a fixed (B, T) bucket; replay costs one graph launch instead of ~60 kernel
+    launches.  Inputs are copied into static device buffers, the RNG seed lives in device memory so
+    every replay draws fresh samples.  ``torch.cuda.CUDAGraph`` is used for capture/replay plumbing
+    only (on ROCm it is hipGraph); every node of the graph is a kernel of ``librnampnn_hip.so``."""
+
+    def __init__(self, model: RNAMPNN, B: int, T: int, temperature: float = 0.1, n_samples: int = 8, T_norm: int = 0):
+        device = model._ensure()
+        self.model, self.B, self.T = model, B, T
+        self.temperature, self.n_samples, self.T_norm = float(temperature), int(n_samples), int(T_norm)
+        self.coords = torch.zeros(B, T, 7, 3, dtype=torch.float32, device=device)
+        self.mask = torch.zeros(B, T, dtype=torch.float32, device=device)
+        self.mask[:, 0] = 1
+        self.seed = torch.zeros(1, dtype=torch.int64, device=device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):                       # warm-up: one-time function attributes, workspace growth
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits, self.samples = self._step()
+
+    def _step(self):
+        logits = self.model.forward(self.coords, self.mask, T_norm=self.T_norm)
+        out = torch.empty(self.n_samples, self.B, self.T, dtype=torch.int8, device=logits.device)
+        with torch.cuda.device(logits.device):
+            _native.check(_native.lib().rnampnn_sample_dev_seed(
+                _ptr(logits), _ptr(self.mask), self.B, self.T, self.temperature, self.n_samples, _ptr(self.seed),
+                _ptr(out), _stream(logits.device)))
+        return logits, out
+
+    @torch.no_grad()
+    def __call__(self, coords: torch.Tensor, mask: torch.Tensor, seed: int = 0):
+        """-> (logits (B,T,4), samples int8 (n_samples,B,T)) - static tensors, overwritten by the next call."""
+        self.coords.copy_(coords, non_blocking=True)
+        self.mask.copy_(mask, non_blocking=True)
+        self.seed.fill_(int(seed) & (2 ** 63 - 1))
+        self.graph.replay()
+        return self.logits, self.samples
