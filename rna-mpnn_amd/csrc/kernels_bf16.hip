@@ -759,65 +759,81 @@ struct ChainW {
     const float* bias[5];     // per layer, natural channel order (last layer padded to NOUT)
 };
 
-struct ChunkRegs { u32x4 v[8]; };       // one chunk of up to 32 fragments (32 KiB / 256 threads) in flight
-
-template <int NFR>
-__device__ __forceinline__ void chunk_load(ChunkRegs& c, const u32x4* __restrict__ src, int tid) {
+// The weight stream is a uniform sequence of 32 KiB chunks (32 fragments; a layer with NKS k-steps
+// packs 32/NKS output blocks per chunk) moved global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no VGPRs) into a 4-slot ring, three chunks ahead of the matrix pipe; each thread issues 8 DMAs per
+// chunk, so "chunk c has landed" is the counted wait vmcnt(8 * chunks issued after c) followed by a
+// raw s_barrier (a __syncthreads() would drain the ring: cdna guide, "Pipelining across barriers").
+#define CH_RING 4
+__device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4* ring, int c, int tid) {
+    const u32x4* src = img + (size_t)c * 2048 + tid;
+    u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63);          // wave-uniform base; the DMA adds lane * 16
 #pragma unroll
-    for (int i = 0; i < (NFR * 64 + 255) / 256; ++i) c.v[i] = src[i * 256 + tid];
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
 }
-template <int NFR>
-__device__ __forceinline__ void chunk_store(const ChunkRegs& c, u32x4* dst, int tid) {
-#pragma unroll
-    for (int i = 0; i < (NFR * 64 + 255) / 256; ++i) dst[i * 256 + tid] = c.v[i];
+__device__ __forceinline__ void chain_wait(int chunks_after) {       // folded to one s_waitcnt after unrolling
+    if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
-// one Linear of the chain: NOB output blocks of NKS k-steps; in[] are the B fragments of its input.
-// On entry `cr` holds the layer's first chunk; each step parks its chunk in the LDS double buffer,
-// issues the loads of the NEXT chunk (NEXT_NKS fragments when it belongs to the next layer) and then
-// runs its MFMAs, so the weight stream stays one chunk ahead of the matrix pipe.
-// GELU + repack into out[] (hidden layers) or f32 store (last layer).
-template <int NKS, int NOB, int NEXT_NKS, bool LAST>
-__device__ __forceinline__ void chain_layer(ChunkRegs& cr, const u32x4* __restrict__& wsrc, u32x4* wbuf, int& parity, int tid,
-                                            int lane, int h, const u32x4 (&in)[32], u32x4 (&out)[32],
-                                            const float* __restrict__ bias, float* __restrict__ yrow, int n_valid, bool row_ok) {
+// one Linear of the chain = NOB output blocks of NKS k-steps = NOB*NKS/32 chunks, starting at global
+// chunk C0 of NCH_T; in[] are the B fragments of its input; GELU + repack into out[] or f32 store.
+template <int NKS, int NOB, int C0, int NCH_T, bool LAST>
+__device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4* ring, int tid, int lane, int h,
+                                            const u32x4 (&in)[32], u32x4 (&out)[32], const float* bias_lds,
+                                            float* __restrict__ yrow, int n_valid, bool row_ok) {
+    constexpr int OPC = 32 / NKS, NCH = NOB / OPC;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        u32x4* buf = wbuf + parity * (32 * 64);
-        chunk_store<NKS>(cr, buf, tid);
-        __syncthreads();
-        parity ^= 1;
-        wsrc += NKS * 64;
-        if (ob + 1 < NOB) chunk_load<NKS>(cr, wsrc, tid);
-        else if (NEXT_NKS > 0) chunk_load<(NEXT_NKS > 0 ? NEXT_NKS : 1)>(cr, wsrc, tid);
-        f32x16 acc = init_vec16(bias + 32 * ob + 16 * h);
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = C0 + ch;
+        chain_wait(NCH_T - 1 - c < 2 ? NCH_T - 1 - c : 2);
+        if (c + 3 < NCH_T) chain_issue(img, ring, c + 3, tid);
+        const u32x4* buf = ring + (c % CH_RING) * 2048;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) acc = mfma32(buf[ks * 64 + lane], in[ks], acc);
-        if (!LAST) {
-            gelu_pack(acc, out[2 * ob], out[2 * ob + 1]);
-        } else if (row_ok) {
+        for (int o = 0; o < OPC; ++o) {
+            const int ob = ch * OPC + o;
+            f32x16 acc = init_vec16(bias_lds + 32 * ob + 16 * h);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c0 = 32 * ob + 16 * h + 4 * v;
-                if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+            for (int ks = 0; ks < NKS; ++ks) acc = mfma32(buf[(o * NKS + ks) * 64 + lane], in[ks], acc);
+            if (!LAST) {
+                gelu_pack(acc, out[2 * ob], out[2 * ob + 1]);
+            } else if (row_ok) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c0 = 32 * ob + 16 * h + 4 * v;
+                    if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 template <int K0, int H, int NH, int NOUT>
 __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx,
         const float* __restrict__ X2, int ldx2, ChainW w, float* __restrict__ Y, int ldy, int n_valid) {
-    __shared__ __attribute__((aligned(16))) u32x4 wbuf[2 * 32 * 64];     // 2 x 32 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [ring 4 x 32 KiB][biases]
+    u32x4* ring = reinterpret_cast<u32x4*>(smem);
+    float* bias_lds = reinterpret_cast<float*>(smem + CH_RING * 32768);
     const int ntot = *ntot_p;
     const int row_blk = blockIdx.x * 128;
     if (row_blk >= ntot) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int row = row_blk + 32 * wave + r;
     const bool row_ok = row < ntot;
+    constexpr int HK = H / 16, HB = H / 32, OB = NOUT / 32;
+    constexpr int NCH0 = HB * (K0 / 16) / 32, NCHH = HB * HK / 32, NCHL = OB * HK / 32, NCH_T = NCH0 + NH * NCHH + NCHL;
+    // biases -> LDS (layer l at l*H), input rows -> B fragments (natural k order; X for k < 128, X2 beyond)
+#pragma unroll
+    for (int l = 0; l < NH + 2; ++l) {
+        const int nb = l == NH + 1 ? NOUT : H;
+        for (int i = tid; i < nb; i += 256) bias_lds[l * H + i] = w.bias[l][i];
+    }
     u32x4 a[32], b[32];
-    // input rows -> B fragments (natural k order): X for k < 128 (or all of K0), X2 beyond
 #pragma unroll
     for (int s = 0; s < K0 / 16; ++s) {
         const int kk = 16 * s + 8 * h;
@@ -826,22 +842,22 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
         if (row_ok) { v0 = *reinterpret_cast<const f32x4*>(src); v1 = *reinterpret_cast<const f32x4*>(src + 4); }
         a[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
     }
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(w.img);
-    int parity = 0;
+    __syncthreads();                                          // biases visible; no DMA is in flight yet
+    const u32x4* img = reinterpret_cast<const u32x4*>(w.img);
+    chain_issue(img, ring, 0, tid);
+    if (NCH_T > 1) chain_issue(img, ring, 1, tid);
+    if (NCH_T > 2) chain_issue(img, ring, 2, tid);
     float* yrow = Y + (size_t)row * ldy;
-    ChunkRegs cr;
-    chunk_load<K0 / 16>(cr, wsrc, tid);
-    constexpr int HK = H / 16, HB = H / 32, OB = NOUT / 32;
-    chain_layer<K0 / 16, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[0], yrow, n_valid, row_ok);
+    chain_layer<K0 / 16, HB, 0, NCH_T, false>(img, ring, tid, lane, h, a, b, bias_lds, yrow, n_valid, row_ok);
     if (NH == 0) {
-        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
+        chain_layer<HK, OB, NCH0, NCH_T, true>(img, ring, tid, lane, h, b, a, bias_lds + H, yrow, n_valid, row_ok);
     } else if (NH == 1) {
-        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
-        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[2], yrow, n_valid, row_ok);
+        chain_layer<HK, HB, NCH0, NCH_T, false>(img, ring, tid, lane, h, b, a, bias_lds + H, yrow, n_valid, row_ok);
+        chain_layer<HK, OB, NCH0 + NCHH, NCH_T, true>(img, ring, tid, lane, h, a, b, bias_lds + 2 * H, yrow, n_valid, row_ok);
     } else {
-        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[1], yrow, n_valid, row_ok);
-        chain_layer<HK, HB, HK, false>(cr, wsrc, wbuf, parity, tid, lane, h, a, b, w.bias[2], yrow, n_valid, row_ok);
-        chain_layer<HK, OB, 0, true>(cr, wsrc, wbuf, parity, tid, lane, h, b, a, w.bias[3], yrow, n_valid, row_ok);
+        chain_layer<HK, HB, NCH0, NCH_T, false>(img, ring, tid, lane, h, b, a, bias_lds + H, yrow, n_valid, row_ok);
+        chain_layer<HK, HB, NCH0 + NCHH, NCH_T, false>(img, ring, tid, lane, h, a, b, bias_lds + 2 * H, yrow, n_valid, row_ok);
+        chain_layer<HK, OB, NCH0 + 2 * NCHH, NCH_T, true>(img, ring, tid, lane, h, b, a, bias_lds + 3 * H, yrow, n_valid, row_ok);
     }
 }
 
@@ -870,9 +886,12 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
     w.img = img;
     for (int i = 0; i < 5; ++i) w.bias[i] = i < NH + 2 ? bias[i] : nullptr;
     dim3 grid((mmax + 127) / 128);
+    const size_t lds = CH_RING * 32768 + (size_t)((NH + 1) * H + NOUT) * sizeof(float);
 #define RN_CHAIN(k0, hh, nh, no) \
     if (K0 == k0 && H == hh && NH == nh && NOUT == no) { \
-        hipLaunchKernelGGL((k_ffn_chain<k0, hh, nh, no>), grid, dim3(256), 0, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; }
+        static bool done = false; \
+        if (!done) { (void)hipFuncSetAttribute((const void*)k_ffn_chain<k0, hh, nh, no>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } \
+        hipLaunchKernelGGL((k_ffn_chain<k0, hh, nh, no>), grid, dim3(256), lds, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; }
     RN_CHAIN(128, 512, 2, 128)
     RN_CHAIN(32, 512, 2, 128)
     RN_CHAIN(256, 512, 0, 32)
