@@ -90,6 +90,11 @@ def main():
     dev = torch.device("cuda", local)
 
     import __graft_entry__ as g
+    if world > 1:                       # one builder per node; the others load the finished library
+        import torch.distributed as dist
+        if local == 0:
+            g.build()
+        dist.barrier()
     g.build()
     from rnampnn.model.rnampnn import RNAMPNN, argmax_recovery
     from rnampnn.utils import synth
@@ -153,6 +158,13 @@ def main():
         bytes_first = k * (128 * w + 4) + 256 * 4 + 2 * 128 * 4            # layer 1: message only, reads e once
         bytes_launch_nt = (bytes_first + (L - 1) * bytes_mid) / L           # mean over the L launches of a forward
         launch_ms = kern_ms / max(launches, 1)
+        traffic = None                  # HBM bytes per launch from PMC counters, when a profile of this workload is committed
+        try:
+            prof = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            if args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch:
+                traffic = prof["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         achieved_gbs = bytes_launch_nt * nt_rank / (launch_ms * 1e-3) / 1e9 if launches else 0.0
         exec_flops_nt = flops_per_nt(k, n_mean, factored=True)
         model_flops_nt = flops_per_nt(k, n_mean)
@@ -166,7 +178,9 @@ def main():
                        "weights": "closed-form deterministic init (3,536,900 params)", "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "fused ResMPNN edge kernel (k_mpnn_*)",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_traffic.json",
+                         "limiter": "VALU issue (GELU, 512 activations per edge per layer) - see DESIGN.md section 4",
                          "launch_ms": launch_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt},
             "mfma": {"model_flops_per_nt": model_flops_nt, "executed_flops_per_nt": exec_flops_nt,

@@ -271,3 +271,27 @@ def test_graph_captured_decode_matches_eager():
         _, again = cap(ct, mt, seed=12)
         assert not torch.equal(again, first)
         assert (again[:, ~mt.bool()] == -1).all()
+
+
+def test_long_rna_and_large_batch_shapes():
+    """A 700-nt RNA (k-NN row > 512, many attention key tiles) and a 300-RNA batch of short RNAs:
+    finite, padded rows zero, f32 path within tolerance of the oracle on the long one."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=30, padding_len=720, num_res_mpnn_layers=2)
+    coords, mask, _ = synth.synth_batch([700, 333], first_index=900)
+    model, sd = _model(hp, state_dict_shapes(hp), "f32")
+    lg = model(torch.from_numpy(coords), torch.from_numpy(mask)).cpu()
+    ref, _ = _oracle(hp, sd, coords, mask)
+    assert (lg - ref).abs().max() < F32_LOGIT_TOL
+    fast, _ = _model(hp, state_dict_shapes(hp), "bf16")
+    lb = fast(torch.from_numpy(coords), torch.from_numpy(mask)).cpu()
+    assert torch.isfinite(lb).all() and (lb - ref).abs().max() < BF16_LOGIT_TOL
+    assert (lb[1, 333:] == 0).all()
+    lens = synth.synth_lengths(300, 1, 40, seed=3)
+    c2, m2, _ = synth.synth_batch(lens, first_index=2000)
+    hp2 = dict(DEFAULT_HPARAMS, num_res_neighbours=30, padding_len=64, num_res_mpnn_layers=2)
+    f2, sd2 = _model(hp2, state_dict_shapes(hp2), "bf16")
+    l2 = f2(torch.from_numpy(c2), torch.from_numpy(m2)).cpu()
+    r2, _ = _oracle(hp2, sd2, c2, m2)
+    assert torch.isfinite(l2).all() and (l2 - r2).abs().max() < BF16_LOGIT_TOL
