@@ -153,6 +153,21 @@ int rnampnn_sample(const float* logits, const float* mask, int32_t B, int32_t T,
 int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, int32_t T, float temperature,
                             int32_t n_samples, const uint64_t* seed_device, int8_t* out, void* stream);
 
+/* -- training ---------------------------------------------------------------------------- */
+/* RNAMPNN.training_step up to loss.backward() (rnampnn.py:187-207, loss rnampnn.py:151-154):
+ * forward, loss = cross_entropy(softmax(logits)[valid], label) (softmax twice, mean over valid
+ * nucleotides) and the gradient of EVERY parameter, f32 kernels, dropout not applied.
+ *   labels (B,T) int32 class ids (ignored on padding); loss: device scalar; logits (B,T,4) optional;
+ *   grad: flat f32 buffer of rnampnn_grad_numel() elements (overwritten); parameter i of
+ *   rnampnn_weight_info() lies at rnampnn_weight_offset(i) - one buffer = one RCCL all-reduce
+ *   (what Lightning DDP does for the reference, rnampnn/utils/train.py:106-117). */
+size_t  rnampnn_train_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
+int64_t rnampnn_grad_numel(rnampnn_handle h);
+int     rnampnn_weight_offset(rnampnn_handle h, int32_t i, int64_t* offset);
+int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float* mask, const int32_t* labels,
+                              int32_t B, int32_t T, int32_t T_norm, float* loss, float* logits, float* grad,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* -- measurement ------------------------------------------------------------------------- */
 /* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when
  * enabled, HIP events bracket each of its launches on the caller's stream; _read synchronises

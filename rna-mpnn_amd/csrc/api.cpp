@@ -843,3 +843,5 @@ extern "C" int rnampnn_sample_dev_seed(const float* logits, const float* mask, i
     HIP_TRY(hipGetLastError());
     return RNAMPNN_OK;
 }
+
+#include "train.inc"

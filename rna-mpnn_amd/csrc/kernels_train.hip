@@ -1,0 +1,465 @@
+// f32 kernels of the TRAINING path (loss + gradients of every parameter), gfx950.
+// Correctness-first building blocks on packed rows: the training forward materialises the per-edge
+// pre-activations ("tape") that the fused inference kernels keep in registers, and the backward pass
+// walks the tape with generic row kernels (GEMM, transposed-reduce GEMM, element-wise GELU',
+// segment mean / scatter, GraphNorm and attention backward).  Reference: rnampnn.py:151-154,187-207
+// (loss = cross_entropy(softmax(logits)[valid], label), mean over valid nucleotides) and the forward
+// lines cited in kernels_f32.hip.  Dropout is not applied (p = 0 semantics).
+#include "kernels_train.h"
+
+static constexpr float kSEPS = 1.0e-6f;
+#define TLD 132
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float x) {     // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ int nrows(const TRows& r) { return *r.ntot * r.mul; }
+
+// ------------------------------------------------------------------------------------------
+// Y[p][0:N] = (beta ? Y : 0) + X[p][0:K] . Wt[0:K][0:N] + bias      (32 x 128 tile, K % 4 == 0)
+__global__ void __launch_bounds__(256) k_tgemm(TRows rows, const float* __restrict__ X, int ldx, int K,
+        const float* __restrict__ Wt, int ldw, const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int beta) {
+    __shared__ __attribute__((aligned(16))) float Xs[32 * TLD];
+    const int R = nrows(rows);
+    const int row0 = blockIdx.x * 32;
+    if (row0 >= R) return;
+    const int tid = threadIdx.x, c = tid & 127, g = tid >> 7;
+    const int cc = blockIdx.y * 128 + c;
+    const int cw = cc < N ? cc : N - 1;
+    float acc[16];
+    const float bv = bias ? bias[cw] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        const int kc = min(128, K - k0);
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, q = idx & 31;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row = row0 + r;
+            if (row < R && q * 4 < kc) v = *reinterpret_cast<const float4*>(X + (size_t)row * ldx + k0 + q * 4);
+            *reinterpret_cast<float4*>(Xs + r * TLD + q * 4) = v;
+        }
+        __syncthreads();
+        const float* xr = Xs + g * 16 * TLD;
+        for (int kk = 0; kk < kc; kk += 4) {
+            const float w0 = Wt[(size_t)(k0 + kk) * ldw + cw], w1 = Wt[(size_t)(k0 + kk + 1) * ldw + cw];
+            const float w2 = Wt[(size_t)(k0 + kk + 2) * ldw + cw], w3 = Wt[(size_t)(k0 + kk + 3) * ldw + cw];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(xr + r * TLD + kk);
+                acc[r] = fmaf(x.x, w0, acc[r]); acc[r] = fmaf(x.y, w1, acc[r]);
+                acc[r] = fmaf(x.z, w2, acc[r]); acc[r] = fmaf(x.w, w3, acc[r]);
+            }
+        }
+        __syncthreads();
+    }
+    if (cc < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + g * 16 + r;
+            if (row < R) {
+                float* y = Y + (size_t)row * ldy + cc;
+                *y = beta ? *y + acc[r] : acc[r];
+            }
+        }
+    }
+}
+void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, int ldw, const float* bias, int N,
+            float* Y, int ldy, int beta, hipStream_t s) {
+    dim3 grid((rows.maxrows + 31) / 32, (N + 127) / 128);
+    hipLaunchKernelGGL(k_tgemm, grid, dim3(256), 0, s, rows, X, ldx, K, Wt, ldw, bias, N, Y, ldy, beta);
+}
+
+// dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block, row range split over blockIdx.z, f32 atomics)
+__global__ void __launch_bounds__(256) k_tgemm_tn(TRows rows, const float* __restrict__ A, int lda, int M,
+        const float* __restrict__ B, int ldb, int K, float* __restrict__ dW, int ldw, int rows_per_split) {
+    __shared__ float As[32][33], Bs[32][33];
+    const int R = nrows(rows);
+    const int p_begin = blockIdx.z * rows_per_split;
+    const int p_end = min(R, p_begin + rows_per_split);
+    if (p_begin >= p_end) return;
+    const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, tm = tid >> 4, tk = tid & 15;        // thread -> m in {tm, tm+16}, k in {tk, tk+16}
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    for (int p0 = p_begin; p0 < p_end; p0 += 32) {
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int r = idx >> 5, cidx = idx & 31;
+            const int p = p0 + r;
+            As[r][cidx] = (p < p_end && m0 + cidx < M) ? A[(size_t)p * lda + m0 + cidx] : 0.f;
+            Bs[r][cidx] = (p < p_end && k0 + cidx < K) ? B[(size_t)p * ldb + k0 + cidx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const float x0 = As[r][tm], x1 = As[r][tm + 16], y0 = Bs[r][tk], y1 = Bs[r][tk + 16];
+            a00 = fmaf(x0, y0, a00); a01 = fmaf(x0, y1, a01); a10 = fmaf(x1, y0, a10); a11 = fmaf(x1, y1, a11);
+        }
+        __syncthreads();
+    }
+    const int mA = m0 + tm, mB = m0 + tm + 16, kA = k0 + tk, kB = k0 + tk + 16;
+    if (mA < M && kA < K) atomicAdd(dW + (size_t)mA * ldw + kA, a00);
+    if (mA < M && kB < K) atomicAdd(dW + (size_t)mA * ldw + kB, a01);
+    if (mB < M && kA < K) atomicAdd(dW + (size_t)mB * ldw + kA, a10);
+    if (mB < M && kB < K) atomicAdd(dW + (size_t)mB * ldw + kB, a11);
+}
+void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw, hipStream_t s) {
+    int splits = (rows.maxrows + 2047) / 2048;
+    if (splits < 1) splits = 1;
+    if (splits > 512) splits = 512;
+    int rps = ((rows.maxrows + splits - 1) / splits + 31) / 32 * 32;
+    dim3 grid((M + 31) / 32, (K + 31) / 32, splits);
+    hipLaunchKernelGGL(k_tgemm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, dW, ldw, rps);
+}
+
+// out[m] += sum_p A[p][m]
+__global__ void __launch_bounds__(256) k_colsum(TRows rows, const float* __restrict__ A, int lda, int M, float* __restrict__ out,
+                                                 int rows_per_block) {
+    const int R = nrows(rows);
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(R, p0 + rows_per_block);
+    for (int m = threadIdx.x; m < M; m += 256) {
+        float s = 0.f;
+        for (int p = p0; p < p1; ++p) s += A[(size_t)p * lda + m];
+        if (p0 < p1) atomicAdd(out + m, s);
+    }
+}
+void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, hipStream_t s) {
+    int rpb = 256;
+    hipLaunchKernelGGL(k_colsum, dim3((rows.maxrows + rpb - 1) / rpb), dim3(256), 0, s, rows, A, lda, M, out, rpb);
+}
+
+// element-wise over rows x D (contiguous, ld = D)
+__global__ void k_gelu_fwd(TRows rows, const float* __restrict__ x, float* __restrict__ y, int D) {
+    const size_t n = (size_t)nrows(rows) * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_f(x[i]);
+}
+__global__ void k_gelu_bwd(TRows rows, const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int D) {
+    const size_t n = (size_t)nrows(rows) * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = dy[i] * gelu_d(pre[i]);
+}
+__global__ void k_add(TRows rows, const float* __restrict__ a, float* __restrict__ dst, int D) {
+    const size_t n = (size_t)nrows(rows) * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += a[i];
+}
+static unsigned ew_grid(const TRows& r, int D) { size_t g = ((size_t)r.maxrows * D + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
+void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, hipStream_t s) {
+    hipLaunchKernelGGL(k_gelu_fwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, x, y, D);
+}
+void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, hipStream_t s) {
+    hipLaunchKernelGGL(k_gelu_bwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, dy, pre, dx, D);
+}
+void t_add(const TRows& rows, const float* a, float* dst, int D, hipStream_t s) {
+    hipLaunchKernelGGL(k_add, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, a, dst, D);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-edge helpers; edge row = p*k + slot, 128 wide
+__global__ void k_edge_features(PackInfo pk, int k, const float* __restrict__ geom, const int* __restrict__ nbr, float* __restrict__ F) {
+    const int E = pk.cu[pk.B] * k;
+    const int eid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (eid >= E) return;
+    float* x = F + (size_t)eid * RN_ERAWP;
+    const int j = nbr[eid];
+    if (j < 0) { for (int i = 0; i < RN_ERAWP; ++i) x[i] = 0.f; return; }
+    const float* gi = geom + (size_t)(eid / k) * RN_GEOM;
+    const float* gj = geom + (size_t)j * RN_GEOM;
+    for (int a = 0; a < 7; ++a)
+        for (int b = 0; b < 7; ++b) {
+            float dx = gi[a * 3] - gj[b * 3], dy = gi[a * 3 + 1] - gj[b * 3 + 1], dz = gi[a * 3 + 2] - gj[b * 3 + 2];
+            x[a * 7 + b] = sqrtf(dx * dx + dy * dy + dz * dz + kSEPS);
+        }
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            x[49 + a * 5 + b] = gi[21 + a * 3] * gj[21 + b * 3] + gi[22 + a * 3] * gj[22 + b * 3] + gi[23 + a * 3] * gj[23 + b * 3];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            x[74 + a * 4 + b] = gi[36 + a * 3] * gj[36 + b * 3] + gi[37 + a * 3] * gj[37 + b * 3] + gi[38 + a * 3] * gj[38 + b * 3];
+    for (int i = RN_ERAW; i < RN_ERAWP; ++i) x[i] = 0.f;
+}
+void t_edge_features(const PackInfo& pk, int k, const float* geom, const int* nbr, float* F, hipStream_t s) {
+    size_t total = (size_t)pk.Nmax * k;
+    hipLaunchKernelGGL(k_edge_features, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, pk, k, geom, nbr, F);
+}
+
+// mode 0: pre[e] += P[i] + Q[j];  mode 1: x[e] = 0 on invalid slots;  mode 2: dst[e] = src1[e] + (valid ? gelu(src2[e]) : 0)
+__global__ void k_edge_elem(PackInfo pk, int k, const int* __restrict__ nbr, int mode, const float* __restrict__ pq,
+                            float* __restrict__ x, const float* __restrict__ src1, const float* __restrict__ src2) {
+    const size_t n = (size_t)pk.cu[pk.B] * k * 32;               // float4 units
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(id & 31);
+        const size_t er = id >> 5;
+        const int j = nbr[er];
+        float4* xp = reinterpret_cast<float4*>(x + er * RN_D) + q;
+        if (mode == 0) {
+            const int i = (int)(er / k);
+            const int jj = j < 0 ? pk.Nmax : (j > pk.Nmax ? pk.Nmax : j);
+            const float4 p = reinterpret_cast<const float4*>(pq + (size_t)i * 256)[q];
+            const float4 qq = reinterpret_cast<const float4*>(pq + (size_t)jj * 256 + 128)[q];
+            float4 v = *xp;
+            v.x += p.x + qq.x; v.y += p.y + qq.y; v.z += p.z + qq.z; v.w += p.w + qq.w;
+            *xp = v;
+        } else if (mode == 1) {
+            if (j < 0) *xp = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            float4 a = reinterpret_cast<const float4*>(src1 + er * RN_D)[q];
+            if (j >= 0) {
+                const float4 g = reinterpret_cast<const float4*>(src2 + er * RN_D)[q];
+                a.x += gelu_f(g.x); a.y += gelu_f(g.y); a.z += gelu_f(g.z); a.w += gelu_f(g.w);
+            }
+            *xp = a;
+        }
+    }
+}
+static unsigned edge_grid(const PackInfo& pk, int k) { size_t g = ((size_t)pk.Nmax * k * 32 + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
+void t_edge_add_pq(const PackInfo& pk, int k, const int* nbr, const float* pq, float* pre, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 0, pq, pre, nullptr, nullptr);
+}
+void t_edge_zero_invalid(const PackInfo& pk, int k, const int* nbr, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, x, nullptr, nullptr);
+}
+void t_edge_residual(const PackInfo& pk, int k, const int* nbr, const float* e_in, const float* pre2, float* e_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 2, nullptr, e_out, e_in, pre2);
+}
+
+// forward: out[p] = h[p] + sum_valid gelu(pre2[e]) / max(cnt,1);   backward: dpre2[e] = valid ? dagg[p]/cnt * gelu'(pre2[e]) : 0
+__global__ void __launch_bounds__(128) k_seg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ pre2,
+                                                  const float* __restrict__ h, float* __restrict__ out) {
+    const int p = blockIdx.x;
+    if (p >= pk.cu[pk.B]) return;
+    const int c = threadIdx.x;
+    float s = 0.f; int cnt = 0;
+    for (int sl = 0; sl < k; ++sl) {
+        if (nbr[(size_t)p * k + sl] >= 0) { s += gelu_f(pre2[((size_t)p * k + sl) * RN_D + c]); ++cnt; }
+    }
+    out[(size_t)p * RN_D + c] = h[(size_t)p * RN_D + c] + s / (float)(cnt > 0 ? cnt : 1);
+}
+__global__ void __launch_bounds__(128) k_seg_mean_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ dagg,
+                                                      const float* __restrict__ pre2, float* __restrict__ dpre2) {
+    const int p = blockIdx.x;
+    if (p >= pk.cu[pk.B]) return;
+    const int c = threadIdx.x;
+    int cnt = 0;
+    for (int sl = 0; sl < k; ++sl) cnt += nbr[(size_t)p * k + sl] >= 0;
+    const float g = dagg[(size_t)p * RN_D + c] / (float)(cnt > 0 ? cnt : 1);
+    for (int sl = 0; sl < k; ++sl) {
+        const size_t o = ((size_t)p * k + sl) * RN_D + c;
+        dpre2[o] = nbr[(size_t)p * k + sl] >= 0 ? g * gelu_d(pre2[o]) : 0.f;
+    }
+}
+void t_seg_mean(const PackInfo& pk, int k, const int* nbr, const float* pre2, const float* h, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_seg_mean, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, pre2, h, out);
+}
+void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const float* pre2, float* dpre2, hipStream_t s) {
+    hipLaunchKernelGGL(k_seg_mean_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, dagg, pre2, dpre2);
+}
+// dpre2e[e] = valid ? de[e] * gelu'(pre2e[e]) : 0   (edge-update residual branch)
+__global__ void k_edge_res_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ de, const float* __restrict__ pre2,
+                               float* __restrict__ dpre2) {
+    const size_t n = (size_t)pk.cu[pk.B] * k * RN_D;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x)
+        dpre2[id] = nbr[id >> 7] >= 0 ? de[id] * gelu_d(pre2[id]) : 0.f;
+}
+void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_res_bwd, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, de, pre2, dpre2);
+}
+// dpq[i][0:128] = sum_slots dpre1 (P part, plain store); dpq[j][128:256] += dpre1 (Q part, atomics; phantom row Nmax absorbs)
+__global__ void __launch_bounds__(128) k_edge_pq_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ dpre1,
+                                                     float* __restrict__ dpq) {
+    const int p = blockIdx.x;
+    if (p >= pk.cu[pk.B]) return;
+    const int c = threadIdx.x;
+    float s = 0.f;
+    for (int sl = 0; sl < k; ++sl) {
+        const float v = dpre1[((size_t)p * k + sl) * RN_D + c];
+        s += v;
+        int j = nbr[(size_t)p * k + sl];
+        if (j >= 0) {
+            if (j > pk.Nmax) j = pk.Nmax;
+            atomicAdd(dpq + (size_t)j * 256 + 128 + c, v);
+        }
+    }
+    dpq[(size_t)p * 256 + c] = s;
+}
+void t_edge_pq_bwd(const PackInfo& pk, int k, const int* nbr, const float* dpre1, float* dpq, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_pq_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, dpre1, dpq);
+}
+
+// ------------------------------------------------------------------------------------------
+// GraphNormalization backward (functional.py:33-46), one workgroup per RNA, D = 128.
+//   y = (x - mu)/sd * scale + shift,  sd^2 = [sum (x-mu)^2 + c mu^2]/n + eps,  c = T_tot - n
+//   dx_i = g_i/sd + dL/dvar * 2 (x_i - mu)/n + dL/dmu / n,   g = dy * scale
+//   dL/dvar = -0.5 sd^-3 sum g_i (x_i - mu),   dL/dmu = -sum g_i / sd + dL/dvar * 2 c mu / n
+__global__ void __launch_bounds__(256) k_gn_bwd(PackInfo pk, const float* __restrict__ x, const float* __restrict__ dy,
+        const float* __restrict__ scale, int t_tot, float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift) {
+    __shared__ float red[4][256];
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const size_t base = (size_t)pk.cu[b] * RN_D;
+    const int c = threadIdx.x & 127, hf = threadIdx.x >> 7;
+    const float* xb = x + base;
+    const float* gb = dy + base;
+    float s = 0.f;
+    for (int r = hf; r < n; r += 2) s += xb[(size_t)r * RN_D + c];
+    red[0][threadIdx.x] = s;
+    __syncthreads();
+    const float mean = (red[0][c] + red[0][c + 128]) / (float)n;
+    float ss = 0.f, sg = 0.f, sgx = 0.f;
+    for (int r = hf; r < n; r += 2) {
+        const float d = xb[(size_t)r * RN_D + c] - mean, g = gb[(size_t)r * RN_D + c];
+        ss = fmaf(d, d, ss); sg += g; sgx = fmaf(g, d, sgx);
+    }
+    red[1][threadIdx.x] = ss; red[2][threadIdx.x] = sg; red[3][threadIdx.x] = sgx;
+    __syncthreads();
+    const float cpad = (float)(t_tot - n), fn = (float)n;
+    const float var = (red[1][c] + red[1][c + 128] + cpad * mean * mean) / fn + kSEPS;
+    const float sd = sqrtf(var), sc = scale[c];
+    const float Sg = (red[2][c] + red[2][c + 128]) * sc, Sgx = (red[3][c] + red[3][c + 128]) * sc;   // sums of g = dy*scale
+    const float dvar = -0.5f * Sgx / (var * sd);
+    const float dmu = -Sg / sd + dvar * 2.f * cpad * mean / fn;
+    float* db = dx + base;
+    for (int r = hf; r < n; r += 2) {
+        const float d = xb[(size_t)r * RN_D + c] - mean;
+        db[(size_t)r * RN_D + c] = gb[(size_t)r * RN_D + c] * sc / sd + dvar * 2.f * d / fn + dmu / fn;
+    }
+    if (hf == 0) {
+        if (dshift) atomicAdd(dshift + c, red[2][c] + red[2][c + 128]);
+        if (dscale) atomicAdd(dscale + c, (red[3][c] + red[3][c + 128]) / sd);
+    }
+}
+void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
+              float* dshift, hipStream_t s) {
+    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, dscale, dshift);
+}
+
+// ------------------------------------------------------------------------------------------
+// attention backward over the valid keys of one RNA (head dim HD), qkv rows [q | k | v], f32.
+// pass 1 (thread per query): row max m, normaliser l, delta = sum_j P_ij (dO_i . v_j), dq_i
+// pass 2 (thread per key):   dv_j = sum_i P_ij dO_i,  dk_j = scale * sum_i dS_ij q_i
+template <int HD>
+__global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
+        float* __restrict__ dqkv, float* __restrict__ stat, int heads) {
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int qi = blockIdx.z * 64 + threadIdx.x;
+    if (blockIdx.z * 64 >= n) return;
+    const int base = pk.cu[b];
+    const bool act = qi < n;
+    const float scale = rsqrtf((float)HD);
+    const float* row = qkv + (size_t)(base + (act ? qi : 0)) * 384 + hd * HD;
+    float q[HD], g[HD], dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = row[d] * scale; g[d] = dO[(size_t)(base + (act ? qi : 0)) * RN_D + hd * HD + d]; dq[d] = 0.f; }
+    float m = -3.0e38f;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kj[d], sc);
+        m = fmaxf(m, sc);
+    }
+    float l = 0.f, delta = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
+        const float* vj = kj + 128;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
+        const float pj = __expf(sc - m);
+        l += pj; delta = fmaf(pj, dp, delta);
+    }
+    delta /= l;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
+        const float* vj = kj + 128;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
+        const float ds = __expf(sc - m) / l * (dp - delta);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, kj[d], dq[d]);
+    }
+    if (act) {
+        float* o = dqkv + (size_t)(base + qi) * 384 + hd * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = dq[d] * scale;
+        float* st = stat + ((size_t)(base + qi) * heads + hd) * 3;
+        st[0] = m; st[1] = l; st[2] = delta;
+    }
+}
+template <int HD>
+__global__ void __launch_bounds__(64) k_attn_bwd_kv(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
+        float* __restrict__ dqkv, const float* __restrict__ stat, int heads) {
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int kj = blockIdx.z * 64 + threadIdx.x;
+    if (blockIdx.z * 64 >= n) return;
+    const int base = pk.cu[b];
+    const bool act = kj < n;
+    const float scale = rsqrtf((float)HD);
+    const float* row = qkv + (size_t)(base + (act ? kj : 0)) * 384 + 128 + hd * HD;
+    float kk[HD], vv[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { kk[d] = row[d]; vv[d] = row[128 + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < n; ++i) {
+        const float* qi = qkv + (size_t)(base + i) * 384 + hd * HD;
+        const float* gi = dO + (size_t)(base + i) * RN_D + hd * HD;
+        const float* st = stat + ((size_t)(base + i) * heads + hd) * 3;
+        float sc = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { sc = fmaf(qi[d] * scale, kk[d], sc); dp = fmaf(gi[d], vv[d], dp); }
+        const float pij = __expf(sc - st[0]) / st[1];
+        const float ds = pij * (dp - st[2]);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pij, gi[d], dv[d]); dk[d] = fmaf(ds, qi[d] * scale, dk[d]); }
+    }
+    if (act) {
+        float* o = dqkv + (size_t)(base + kj) * 384 + 128 + hd * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { o[d] = dk[d]; o[128 + d] = dv[d]; }
+    }
+}
+int t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat, hipStream_t s) {
+    dim3 grid(pk.B, heads, (pk.T + 63) / 64);
+    const int hd = RN_D / heads;
+#define RN_ATT(H) \
+    if (hd == H) { hipLaunchKernelGGL(k_attn_bwd_q<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads); \
+                   hipLaunchKernelGGL(k_attn_bwd_kv<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads); return 0; }
+    RN_ATT(16) RN_ATT(32) RN_ATT(8) RN_ATT(64)
+#undef RN_ATT
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// loss = mean_valid CE(softmax(logits), label)  (softmax applied twice, rnampnn.py:151-154,201-204)
+__global__ void __launch_bounds__(256) k_loss_grad(PackInfo pk, const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                   float* __restrict__ dlogits, float* __restrict__ loss) {
+    const int ntot = pk.cu[pk.B];
+    float local = 0.f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < ntot; p += gridDim.x * blockDim.x) {
+        const int b = pk.node_b[p];
+        const int y = labels[(size_t)b * pk.T + (p - pk.cu[b])];
+        const float4 z = reinterpret_cast<const float4*>(logits)[p];
+        float zz[4] = {z.x, z.y, z.z, z.w}, pr[4], q[4];
+        float mx = fmaxf(fmaxf(zz[0], zz[1]), fmaxf(zz[2], zz[3])), s = 0.f;
+        for (int c = 0; c < 4; ++c) { pr[c] = expf(zz[c] - mx); s += pr[c]; }
+        for (int c = 0; c < 4; ++c) pr[c] /= s;
+        float mp = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3])), s2 = 0.f;
+        for (int c = 0; c < 4; ++c) { q[c] = expf(pr[c] - mp); s2 += q[c]; }
+        for (int c = 0; c < 4; ++c) q[c] /= s2;
+        local += -logf(q[y]);
+        float dp[4], dot = 0.f;
+        for (int c = 0; c < 4; ++c) { dp[c] = (q[c] - (c == y ? 1.f : 0.f)) / (float)ntot; dot += dp[c] * pr[c]; }
+        float4 o;
+        o.x = pr[0] * (dp[0] - dot); o.y = pr[1] * (dp[1] - dot); o.z = pr[2] * (dp[2] - dot); o.w = pr[3] * (dp[3] - dot);
+        reinterpret_cast<float4*>(dlogits)[p] = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if ((threadIdx.x & 63) == 0 && ntot > 0) atomicAdd(loss, local / (float)ntot);
+}
+void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, hipStream_t s) {
+    int grid = (pk.Nmax + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_loss_grad, dim3(grid), dim3(256), 0, s, pk, logits, labels, dlogits, loss);
+}

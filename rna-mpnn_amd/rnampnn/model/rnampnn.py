@@ -113,6 +113,55 @@ class RNAMPNN(NativeModule):
         return ["".join(REVERSE_VOCAB[int(i)] for i in row[row >= 0]) for row in pred]
 
     # ------------------------------------------------------------------ training / validation surface
+    def loss_and_grad(self, sequences: torch.Tensor, coords: torch.Tensor, mask: torch.Tensor, T_norm: int = 0,
+                      return_logits: bool = False):
+        """``training_step`` + ``loss.backward()`` of the reference (rnampnn.py:187-207) in one native call:
+        forward, loss = cross_entropy(softmax(logits)[valid], label) and the gradient of every parameter
+        (f32 HIP kernels; dropout is not applied).  ``sequences`` is the collate's one-hot (B,T,4) or class
+        ids (B,T).  Afterwards every ``p.grad`` is a view into ONE flat buffer (``self.flat_grad``), so a
+        data-parallel job all-reduces gradients with a single RCCL call (``allreduce_gradients``)."""
+        device = self._ensure()
+        B, T = int(coords.shape[0]), int(coords.shape[1])
+        c, m = _prep(coords, device), _prep(mask, device)
+        lab = sequences.argmax(dim=-1) if sequences.dim() == 3 else sequences
+        lab = _prep(lab, device, torch.int32)
+        lib = _native.lib()
+        if getattr(self, "flat_grad", None) is None or self.flat_grad.device != device:
+            n = int(lib.rnampnn_grad_numel(self._handle.ptr))
+            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+            named = dict(self.named_parameters())
+            for i, (key, _) in enumerate(self._handle.weight_schema()):
+                off = C.c_int64()
+                _native.check(lib.rnampnn_weight_offset(self._handle.ptr, i, C.byref(off)))
+                p = named[key]
+                p.grad = self.flat_grad[off.value: off.value + p.numel()].view(p.shape)
+        loss = torch.zeros((), dtype=torch.float32, device=device)
+        logits = torch.empty(B, T, 4, dtype=torch.float32, device=device) if return_logits else None
+        need = int(lib.rnampnn_train_workspace_bytes(self._handle.ptr, B, T))
+        if getattr(self, "_tws", None) is None or self._tws.numel() < need + 256 or self._tws.device != device:
+            self._tws = None
+            self._tws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        base = self._tws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        with torch.cuda.device(device):
+            _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm),
+                                                    _ptr(loss), _ptr(logits), _ptr(self.flat_grad), C.c_void_p(aligned),
+                                                    C.c_size_t(self._tws.numel() - (aligned - base)), _stream(device)))
+        return (loss, logits) if return_logits else loss
+
+    def training_step(self, batch):
+        """rnampnn.py:187-207.  Returns the loss; gradients are already in ``p.grad`` (no autograd graph)."""
+        sequences, coords, mask, _ = batch
+        return self.loss_and_grad(sequences, coords, mask)
+
+    def allreduce_gradients(self) -> None:
+        """Average ``flat_grad`` over the ranks of the default process group (RCCL on the GPUs): the one
+        collective of data-parallel training (Lightning DDP in the reference, utils/train.py:106-117)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self.flat_grad.div_(dist.get_world_size())
+
     @staticmethod
     def mix_loss(valid_probs, valid_sequences):
         # rnampnn.py:151-154 - cross_entropy applied to PROBABILITIES (softmax twice), a reference quirk

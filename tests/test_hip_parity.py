@@ -295,3 +295,47 @@ def test_long_rna_and_large_batch_shapes():
     l2 = f2(torch.from_numpy(c2), torch.from_numpy(m2)).cpu()
     r2, _ = _oracle(hp2, sd2, c2, m2)
     assert torch.isfinite(l2).all() and (l2 - r2).abs().max() < BF16_LOGIT_TOL
+
+
+@pytest.mark.parametrize("cfg", ["default_small", "alt_attn"])
+def test_loss_and_gradients_match_oracle_autograd(cfg):
+    """Training path: loss and the gradient of every parameter vs torch autograd through the CPU oracle
+    (same double-softmax loss, rnampnn.py:151-154).  f32, dropout off."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    from oracle import rnampnn_oracle as O
+    if cfg == "default_small":
+        hp = dict(DEFAULT_HPARAMS, num_res_neighbours=6, num_res_mpnn_layers=3, padding_len=24, embedding_ffn_dim=128,
+                  post_fusion_ffn_dim=128, num_raw_ffn_dim=128, readout_hidden_dim=128)
+    else:   # attention in the embedding, single-Linear edge MLP / readout (the train.py:9-43 shape)
+        hp = dict(DEFAULT_HPARAMS, num_res_neighbours=4, num_embedding_attn_layers=1, embedding_ffn_dim=64,
+                  num_embedding_ffn_layers=1, num_res_mpnn_layers=2, num_mpnn_edge_layers=1, num_post_fusion_attn_layers=1,
+                  post_fusion_ffn_dim=64, num_post_fusion_ffn_layers=1, num_raw_ffn_layers=1, num_raw_ffn_dim=64,
+                  readout_hidden_dim=64, num_readout_layers=1, padding_len=24)
+    lens = [14, 5, 9]
+    coords, mask, labels = synth.synth_batch(lens, first_index=40)
+    model, sd_np = _model(hp, state_dict_shapes(hp), "f32")
+    onehot = torch.nn.functional.one_hot(torch.from_numpy(labels), 4).float()
+    loss, logits = model.loss_and_grad(onehot, torch.from_numpy(coords), torch.from_numpy(mask), return_logits=True)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    ocfg = O.OracleConfig(**{k: v for k, v in hp.items() if k in O.OracleConfig.__dataclass_fields__})
+    ref_logits, _ = O.forward(torch.from_numpy(coords), torch.from_numpy(mask), sd, ocfg)
+    ref_loss = O.loss_double_softmax(ref_logits, torch.from_numpy(mask), torch.from_numpy(labels))
+    ref_loss.backward()
+    assert (logits.cpu() - ref_logits.detach()).abs().max() < 1e-4
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    worst = 0.0
+    for key, p in model.named_parameters():
+        g = p.grad.detach().cpu()
+        r = sd[key].grad
+        r = torch.zeros_like(g) if r is None else r
+        scale = float(r.abs().max()) + 1e-7
+        err = float((g - r).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 2e-3 or float((g - r).abs().max()) < 1e-7, f"{key}: rel grad error {err:.2e}"
+    # one Adam step with the reference optimiser moves the parameters
+    opt = model.configure_optimizers()[0][0]
+    before = model.readout.readout_layers._modules["0"].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.readout.readout_layers._modules["0"].weight.detach())
+    print(f"{cfg}: loss {float(loss):.6f}, worst relative gradient error {worst:.2e}")
