@@ -85,3 +85,32 @@ def test_two_rank_sharding_reproduces_single_rank():
     for r in range(world):
         for i, lg in ret[r]["logits"].items():
             assert np.abs(lg - full[i, :lens[i]].numpy()).max() < 1e-5
+
+
+def _grad_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "rna-mpnn_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rnampnn.model.rnampnn import RNAMPNN
+    m = RNAMPNN(precision="f32", num_res_mpnn_layers=1)
+    n = sum(p.numel() for p in m.parameters())
+    m.flat_grad = torch.full((n,), float(rank + 1))            # stands in for the HIP backward's flat buffer
+    off = 0
+    for p in m.parameters():                                   # grads are views of the flat buffer
+        p.grad = m.flat_grad[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    m.allreduce_gradients()
+    ret[rank] = (float(m.flat_grad.min()), float(m.flat_grad.max()), float(next(m.parameters()).grad.mean()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_ranks():
+    """One flat all-reduce averages every parameter gradient (views of the flat buffer follow)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert ret[r] == (1.5, 1.5, 1.5)
