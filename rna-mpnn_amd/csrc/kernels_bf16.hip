@@ -241,22 +241,22 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
 }
 
 // First Linear (+GELU) of an e-MLP: hb[2mb + s'] = bf16(GELU(P[i] + Q[j] + Wc . e)), channel blocks mb.
-// P row (f32, the same address for every lane of a half: a broadcast load) initialises the
-// accumulator; the gathered Q row arrives as bf16 in qv[2mb], qv[2mb+1] (prefetched by the caller).
+// P row (f32, the same address for every lane of a half: a broadcast LDS read) initialises the
+// accumulator.  The gathered Q row (bf16, fetched in the e-fragment layout: qv[s] = channels 16s+8h..)
+// is added by the MATRIX pipe, not the VALU: two extra MFMAs per channel block whose A operand is
+// the constant 0/1 matrix that routes channel 16s+8h+j to the accumulator row holding it
+// (perm[s & 1], identical for every block) - exact (x 1.0, f32 accumulate) and free while the
+// kernel is VALU-issue bound.
 __device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lane, const u32x4 (&ef)[8],
-                                          const float* __restrict__ pp, const u32x4 (&qv)[8], u32x4 (&hb)[8]) {
+                                          const float* __restrict__ pp, const u32x4 (&qv)[8], const u32x4 (&perm)[2],
+                                          u32x4 (&hb)[8]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         f32x16 acc = init_vec16(pp + 32 * mb);
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc = mfma32(img[(mb * 8 + s) * 64 + lane], ef[s], acc);
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[8 * v + 2 * t] += lo_bf(qv[2 * mb + v][t]);
-                acc[8 * v + 2 * t + 1] += hi_bf(qv[2 * mb + v][t]);
-            }
+        acc = mfma32(perm[0], qv[2 * mb], acc);
+        acc = mfma32(perm[1], qv[2 * mb + 1], acc);
         gelu_pack(acc, hb[2 * mb], hb[2 * mb + 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -316,6 +316,28 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     const int zero_row = pk.Nmax;
     const int stride = gridDim.x * NW;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // constant routing fragments: accumulator row r of a channel block holds channel 16*sp + c16 of it
+    u32x4 perm[2];
+    {
+        const int c16 = (r & 3) + 4 * (r >> 3), sp_r = (r >> 2) & 1, jstar = c16 - 8 * h;      // element jstar of this lane's k-half
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                perm[sp][t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
+    }
+    // bias of the last message Linear through the matrix pipe as well: A = [1, 1, 0, ...] (k = 0, 1 of lane half 0),
+    // B = [hi(b), lo(b), 0, ...] for output channel 32nb + r  (b = hi + lo to ~16 bits)
+    const u32x4 ones_a = {h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u};
+    unsigned bw[4] = {0u, 0u, 0u, 0u};
+    if (DO_MSG && h == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float bf = lds_b2m[32 * nb + r];
+            const unsigned hi = pack2(bf, 0.f) & 0xffffu;
+            bw[nb] = hi | (pack2(bf - __uint_as_float(hi << 16), 0.f) << 16);
+        }
+    }
 
     int blk = blockIdx.x * NW + wave;
     if (blk >= nblocks) return;
@@ -343,9 +365,9 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         // gather of this block's Q_e row (bf16, 2 x 16 B per channel block) and the next block's indices
         u32x4 qe[8], qm[8];
         if (DO_EDGE) {
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_e + (size_t)qrow * RN_D + 16 * h);
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_e + (size_t)qrow * RN_D) + h;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) { qe[2 * mb] = qp[4 * mb]; qe[2 * mb + 1] = qp[4 * mb + 1]; }
+            for (int s = 0; s < 8; ++s) qe[s] = qp[2 * s];
         }
         BlockLane bn = bl;
         if (has_next) bn = block_lane(nblk, npb, k, ntot, r, nbr);
@@ -358,15 +380,15 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         u32x4 hb[8], efn[8];
         STAMP(t1);
         if (DO_EDGE) {
-            mlp_first(img_e, lane, ef, SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : lds_p + 16 * h, qe, hb);
+            mlp_first(img_e, lane, ef, SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : lds_p + 16 * h, qe, perm, hb);
         }
         STAMP(t2);
 #if RN_MPNN_PREFETCH
         // Q_m gather and the next block's e fragments: in flight during the following Linear(s)
         if (DO_MSG) {
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D + 16 * h);
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D) + h;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) { qm[2 * mb] = qp[4 * mb]; qm[2 * mb + 1] = qp[4 * mb + 1]; }
+            for (int s = 0; s < 8; ++s) qm[s] = qp[2 * s];
         }
 #endif
         {
@@ -406,22 +428,20 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         STAMP(t4);
 #if !RN_MPNN_PREFETCH
         if (DO_MSG) {       // 3 waves per SIMD cover this gather; issuing it here keeps the kernel within 168 VGPRs
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D + 16 * h);
+            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D) + h;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) { qm[2 * mb] = qp[4 * mb]; qm[2 * mb + 1] = qp[4 * mb + 1]; }
+            for (int s = 0; s < 8; ++s) qm[s] = qp[2 * s];
         }
 #endif
         if (DO_MSG) {
-            mlp_first(img_m, lane, ef, SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : lds_p + 128 + 16 * h, qm, hb);
+            mlp_first(img_m, lane, ef, SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : lds_p + 128 + 16 * h, qm, perm, hb);
             STAMP(t5);
             const unsigned vmask = (unsigned)(__ballot(bl.ok && bl.valid) & 0xffffffffull);   // bit r = edge r is real
             // last Linear un-transposed: rows = edges of the block (registers), columns = channels 32nb + r
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const float b = lds_b2m[32 * nb + r];
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = b;
+                const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 acc = mfma32(ones_a, u32x4{bw[nb], 0u, 0u, 0u}, zacc);          // bias
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) acc = mfma32(hb[ks], img_m[2048 + (nb * 8 + ks) * 64 + lane], acc);
 #pragma unroll
