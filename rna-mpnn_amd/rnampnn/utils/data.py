@@ -1,42 +1,31 @@
-"""Host-side input contract of the hot path: the reference's collate layout and ``separate``
-(``rnampnn/utils/data.py:110-142, 594-604``).  Dataset / PDB parsing / plotting of that file are
-host I/O outside the hot path and are not mirrored."""
+"""Host-side input contract of the hot path: the batch layout the reference's collate produces and
+``separate`` (``rnampnn/utils/data.py:110-142, 594-604``).  Dataset / PDB parsing / plotting of that
+file are host I/O outside the hot path and are not mirrored."""
 from __future__ import annotations
 
-from typing import Dict, List, Tuple, Union
+from typing import Dict, List, Sequence, Tuple, Union
 
 import torch
+from torch.nn.utils.rnn import pad_sequence
 
-from ..config.glob import NUM_MAIN_SEQ_ATOMS, NUM_RES_TYPES
+Item = Dict[str, Union[str, torch.Tensor]]
 
 
-def featurize(batch: List[Dict[str, Union[str, torch.Tensor]]]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[str]]:
-    """Pad a list of {'sequence' (L,4) one-hot, 'coordinates' (L,7,3), 'id'} items to the batch
-    max length: sequences (B,T,4), coords (B,T,7,3) zero-padded, mask (B,T) prefix of ones, ids."""
-    batch_size = len(batch)
-    max_len = max(item['sequence'].shape[0] for item in batch)
-    sequences = torch.zeros((batch_size, max_len, NUM_RES_TYPES), dtype=torch.float32)
-    coords = torch.zeros((batch_size, max_len, NUM_MAIN_SEQ_ATOMS, 3), dtype=torch.float32)
-    mask = torch.zeros((batch_size, max_len), dtype=torch.float32)
-    ids = []
-    for i, item in enumerate(batch):
-        n = item['sequence'].shape[0]
-        sequences[i, :n] = item['sequence']
-        coords[i, :n] = item['coordinates']
-        mask[i, :n] = 1
-        ids.append(item['id'])
-    return sequences, coords, mask, ids
+def featurize(batch: Sequence[Item]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[str]]:
+    """Collate {'sequence' (L,4) one-hot, 'coordinates' (L,7,3), 'id'} items to the batch max length ->
+    (sequences (B,T,4), coords (B,T,7,3), mask (B,T), ids); zero padding, mask = prefix of ones
+    (the layout every kernel of this package assumes)."""
+    seqs = pad_sequence([it['sequence'].to(torch.float32) for it in batch], batch_first=True)
+    xyz = pad_sequence([it['coordinates'].to(torch.float32) for it in batch], batch_first=True)
+    lengths = torch.tensor([it['sequence'].shape[0] for it in batch])
+    mask = (torch.arange(seqs.shape[1]).unsqueeze(0) < lengths.unsqueeze(1)).to(torch.float32)
+    return seqs, xyz, mask, [it['id'] for it in batch]
 
 
 def separate(concat: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
-    """Split a concatenation of per-RNA vectors back into a zero-padded (B, max_len) tensor."""
-    lens = [int(x) for x in lengths.tolist()]
-    out = torch.zeros((len(lens), max(lens) if lens else 0), dtype=concat.dtype)
-    start = 0
-    for i, n in enumerate(lens):
-        out[i, :n] = concat[start:start + n]
-        start += n
-    return out
+    """Inverse of boolean-mask selection: a concatenation of per-RNA vectors -> zero-padded (B, max_len)."""
+    pieces = torch.split(concat, [int(n) for n in lengths.tolist()])
+    return pad_sequence(list(pieces), batch_first=True) if pieces else concat.new_zeros((0, 0))
 
 
 def check_prefix_mask(mask: torch.Tensor) -> None:

@@ -88,3 +88,22 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "rnampnn_oracle" not in text, f
+
+
+def test_collate_and_separate_contract():
+    """featurize / separate reproduce the reference collate layout (utils/data.py:110-142, 594-604)."""
+    import torch
+    from rnampnn.utils.data import check_prefix_mask, featurize, separate
+    from rnampnn.config.glob import VOCAB, REVERSE_VOCAB, NUM_RES_TYPES, NUM_MAIN_SEQ_ATOMS
+    assert VOCAB == {'A': 0, 'U': 1, 'C': 2, 'G': 3} and REVERSE_VOCAB[3] == 'G' and NUM_RES_TYPES == 4 and NUM_MAIN_SEQ_ATOMS == 7
+    items = [{'sequence': torch.eye(4)[torch.tensor([0, 1, 2])], 'coordinates': torch.ones(3, 7, 3), 'id': 'a'},
+             {'sequence': torch.eye(4)[torch.tensor([3, 3, 1, 0, 2])], 'coordinates': 2 * torch.ones(5, 7, 3), 'id': 'b'}]
+    seq, xyz, mask, ids = featurize(items)
+    assert seq.shape == (2, 5, 4) and xyz.shape == (2, 5, 7, 3) and ids == ['a', 'b']
+    assert mask.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]] and float(xyz[0, 3:].abs().sum()) == 0
+    check_prefix_mask(mask)
+    with pytest.raises(ValueError):
+        check_prefix_mask(torch.tensor([[1., 0., 1.]]))
+    flat = torch.arange(8.)
+    sep = separate(flat, torch.tensor([3, 5]))
+    assert sep.tolist() == [[0, 1, 2, 0, 0], [3, 4, 5, 6, 7]]
