@@ -27,13 +27,12 @@ class ResFeature(NativeModule):
                  res_edge_embedding_dim: int = DEFAULT_HIDDEN_DIM, num_edge_layers: int = 2, dropout: float = 0.1,
                  precision: Optional[str] = None):
         super().__init__()
-        # same assertions as feature.py:169-179
-        assert num_inside_dist_atoms >= 2, f"num_inside_dist_atoms({num_inside_dist_atoms}) must be at least 2 for distance calculation."
-        assert num_inside_angle_atoms >= 3, f"num_inside_angle_atoms({num_inside_angle_atoms}) must be at least 3 for angle calculation."
-        assert num_inside_dihedral_atoms >= 4, f"num_inside_dihedral_atoms({num_inside_dihedral_atoms}) must be at least 4 for dihedral calculation."
-        assert num_cross_dist_atoms >= 2, f"num_cross_dist_atoms({num_cross_dist_atoms}) must be at least 2 for cross distance calculation."
-        assert num_cross_angle_atoms >= 3, f"num_cross_angle_atoms({num_cross_angle_atoms}) must be at least 3 for cross angle calculation."
-        assert num_cross_dihedral_atoms >= 4, f"num_cross_dihedral_atoms({num_cross_dihedral_atoms}) must be at least 4 for cross dihedral calculation."
+        # AssertionError on impossible atom counts, as feature.py:169-179 raises
+        minimum = {"dist": 2, "angle": 3, "dihedral": 4}
+        for scope, counts in (("inside", (num_inside_dist_atoms, num_inside_angle_atoms, num_inside_dihedral_atoms)),
+                              ("cross", (num_cross_dist_atoms, num_cross_angle_atoms, num_cross_dihedral_atoms))):
+            for (kind, least), got in zip(minimum.items(), counts):
+                assert got >= least, f"num_{scope}_{kind}_atoms = {got}: a {kind} feature needs at least {least} atoms"
         if (num_inside_dist_atoms, num_inside_angle_atoms, num_inside_dihedral_atoms, num_cross_dist_atoms,
                 num_cross_angle_atoms, num_cross_dihedral_atoms) != (7, 6, 6, 7, 6, 6):
             raise NotImplementedError("the HIP featurisation kernels are built for atom counts 7/6/6")
