@@ -82,12 +82,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (not used by the driver): RNAMPNN_BENCH_BACKEND=gloo and RNAMPNN_BENCH_ONE_GPU=1 let the
+    # N>1 path run with every rank on GPU 0 of a one-GPU box
+    backend = os.environ.get("RNAMPNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("RNAMPNN_BENCH_ONE_GPU") == "1":
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the two scalar reductions live
 
     import __graft_entry__ as g
     if world > 1:                       # one builder per node; the others load the finished library
@@ -135,10 +144,10 @@ def main():
     nt_total, t_max = float(nt_rank), elapsed
     if world > 1:
         import torch.distributed as dist
-        buf = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        buf = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
         t_max = float(buf[0])
-        cnt = torch.tensor([nt_rank], device=dev, dtype=torch.float64)
+        cnt = torch.tensor([nt_rank], device=red_dev, dtype=torch.float64)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         nt_total = float(cnt[0])
     value = nt_total * args.steps / t_max
