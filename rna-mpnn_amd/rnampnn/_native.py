@@ -10,6 +10,9 @@ import ctypes as C
 import os
 from typing import Optional
 
+import torch  # noqa: F401  - FIRST: the process must use ONE HIP runtime (the one PyTorch-ROCm loads); loading
+#                librnampnn_hip.so before torch would bring in a second libamdhip64 that sees no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librnampnn_hip.so")
 
