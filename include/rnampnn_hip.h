@@ -116,6 +116,17 @@ size_t rnampnn_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
 int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Packed (var-len) form of the same forward - SURVEY.md section 8 row F1: the reference's collate pads every
+ * RNA to the batch max_len (rnampnn/utils/data.py:110-142); here the caller hands over the valid residues
+ * only, back to back: coords_packed (N_total,7,3) f32, cu_seqlens (B+1) i32 on the device (exclusive prefix
+ * sum of the lengths), T_max = longest RNA (host value; decides the phantom-edge rule exactly as a batch
+ * padded to T_max would), T_norm as above (0 = T_max).  Outputs are packed rows as well:
+ * logits_packed (N_total,4), embedding_packed (N_total,256); either may be null. */
+size_t rnampnn_workspace_bytes_packed(rnampnn_handle h, int32_t B, int32_t N_total);
+int rnampnn_forward_packed(rnampnn_handle h, const float* coords_packed, const int32_t* cu_seqlens, int32_t B,
+                           int32_t N_total, int32_t T_max, int32_t T_norm, float* logits_packed,
+                           float* embedding_packed, void* workspace, size_t workspace_bytes, void* stream);
+
 /* -- stage entry points (parity tests and the standalone reference classes) -------------- */
 /* ResMPNN.forward / ResMPNN.message (mpnn.py:154-194, 267-294) for layer `layer` (0-based) on
  * caller-supplied h (B,T,128), e (B,T,k,128), edge_index (B,T,k) i64.  msg_out (B,T,k,128),

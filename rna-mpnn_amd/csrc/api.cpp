@@ -412,10 +412,10 @@ struct Ws {                       // workspace carve (all offsets 256-byte align
     size_t total;
 };
 
-static size_t carve(const rnampnn_ctx* c, int B, int T, char* base, Ws* w) {
+static size_t carve(const rnampnn_ctx* c, int B, size_t Nmax, char* base, Ws* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
-    size_t Nmax = (size_t)B * T, k = c->cfg.num_res_neighbours, F = c->fmax;
+    size_t k = c->cfg.num_res_neighbours, F = c->fmax;
     size_t esz = c->cfg.precision == RNAMPNN_PREC_BF16 ? sizeof(bf16_t) : sizeof(float);
     Ws tmp;
     Ws& r = w ? *w : tmp;
@@ -446,7 +446,11 @@ static size_t carve(const rnampnn_ctx* c, int B, int T, char* base, Ws* w) {
 
 extern "C" size_t rnampnn_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T) {
     if (!h || B <= 0 || T <= 0) return 0;
-    return carve(h, B, T, nullptr, nullptr);
+    return carve(h, B, (size_t)B * T, nullptr, nullptr);
+}
+extern "C" size_t rnampnn_workspace_bytes_packed(rnampnn_handle h, int32_t B, int32_t N_total) {
+    if (!h || B <= 0 || N_total <= 0) return 0;
+    return carve(h, B, (size_t)N_total, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -572,22 +576,26 @@ static void unpack_e(Run& r, float* dst) {
     }
 }
 
-static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+// mask != null: padded API tensors (B,T); cu_seqlens != null: packed input of n_total rows (T = longest RNA)
+static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, void* ws, size_t ws_bytes, void* stream,
+                     const int32_t* cu_seqlens = nullptr, int n_total = 0) {
     if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
     if (!h->finalized) return fail(RNAMPNN_ERR_WEIGHTS, "weights not finalized (call rnampnn_finalize_weights)");
-    if (!mask || !ws || B <= 0 || T <= 0) return fail(RNAMPNN_ERR_BAD_ARG, "null pointer or non-positive B/T");
-    if ((long long)B * T > 0x3fffffffLL / (h->cfg.num_res_neighbours * 4))
-        return fail(RNAMPNN_ERR_BAD_ARG, "B*T too large for 32-bit edge indexing; split the batch");
-    size_t need = carve(h, B, T, nullptr, nullptr);
+    if ((!mask && !cu_seqlens) || !ws || B <= 0 || T <= 0) return fail(RNAMPNN_ERR_BAD_ARG, "null pointer or non-positive B/T");
+    const long long nmax = cu_seqlens ? (long long)n_total : (long long)B * T;
+    if (nmax <= 0 || nmax > 0x3fffffffLL / (h->cfg.num_res_neighbours * 4))
+        return fail(RNAMPNN_ERR_BAD_ARG, "row count out of range for 32-bit edge indexing; split the batch");
+    size_t need = carve(h, B, (size_t)nmax, nullptr, nullptr);
     if (ws_bytes < need) return fail(RNAMPNN_ERR_WORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, need);
     if (((uintptr_t)ws & 255) != 0) return fail(RNAMPNN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
     r.c = h;
     r.s = (hipStream_t)stream;
     r.fast = h->cfg.precision == RNAMPNN_PREC_BF16;
-    carve(h, B, T, (char*)ws, &r.w);
+    carve(h, B, (size_t)nmax, (char*)ws, &r.w);
     r.pk.len = r.w.len; r.pk.cu = r.w.cu; r.pk.node_b = r.w.node_b;
-    r.pk.B = B; r.pk.T = T; r.pk.Nmax = B * T;
-    launch_lengths(mask, r.pk, r.s);
+    r.pk.B = B; r.pk.T = T; r.pk.Nmax = (int)nmax; r.pk.packed_in = cu_seqlens ? 1 : 0;
+    if (cu_seqlens) launch_lengths_from_cu(cu_seqlens, r.pk, r.s);
+    else launch_lengths(mask, r.pk, r.s);
     // the all-zero row Nmax of every gathered node table (phantom neighbour / invalid slot)
     size_t Nmax = r.pk.Nmax;
     HIP_TRY(hipMemsetAsync(r.w.hA + Nmax * RN_D, 0, RN_D * sizeof(float), r.s));
@@ -603,6 +611,10 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
     return RNAMPNN_OK;
 }
 
+// packed outputs of the packed-input entry point (null for the padded API)
+struct PackedOut { float* logits; float* embedding; int n_total; };
+static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, const PackedOut* po);
+
 extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, void* ws, size_t ws_bytes, void* stream) {
     if (!io || !io->coords) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_forward: null io/coords");
     if (io->stop_after == 0 && !io->logits && !io->embedding)
@@ -610,6 +622,26 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
     Run r;
     int rc = begin_run(r, h, io->mask, io->B, io->T, ws, ws_bytes, stream);
     if (rc) return rc;
+    return forward_core(r, h, io, nullptr);
+}
+
+extern "C" int rnampnn_forward_packed(rnampnn_handle h, const float* coords_packed, const int32_t* cu_seqlens, int32_t B,
+                                      int32_t N_total, int32_t T_max, int32_t T_norm, float* logits_packed,
+                                      float* embedding_packed, void* ws, size_t ws_bytes, void* stream) {
+    if (!coords_packed || !cu_seqlens || (!logits_packed && !embedding_packed))
+        return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_forward_packed: null input or no output");
+    Run r;
+    int rc = begin_run(r, h, nullptr, B, T_max, ws, ws_bytes, stream, cu_seqlens, N_total);
+    if (rc) return rc;
+    RnaMpnnForwardIO io;
+    memset(&io, 0, sizeof(io));
+    io.coords = coords_packed; io.B = B; io.T = T_max; io.T_norm = T_norm;
+    PackedOut po{logits_packed, embedding_packed, N_total};
+    return forward_core(r, h, &io, &po);
+}
+
+static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, const PackedOut* po) {
+    int rc = RNAMPNN_OK;
     rnampnn_ctx* c = h;
     const RnaMpnnConfig& g = c->cfg;
     if (io->T > g.padding_len)
@@ -691,21 +723,29 @@ extern "C" int rnampnn_forward(rnampnn_handle h, const RnaMpnnForwardIO* io, voi
         launch_unpack_nodes_strided(r.pk, w.n0, RN_D, RN_D, io->embedding, 2 * RN_D, 0, s);
         launch_unpack_nodes_strided(r.pk, w.n2, RN_D, RN_D, io->embedding, 2 * RN_D, RN_D, s);
     }
-    if (io->logits && run_chain(r, c->readout_chain, c->readout, w.n0, RN_D, w.n2, RN_D, w.logits_p, 4)) {
-        launch_unpack_nodes(r.pk, w.logits_p, 4, 4, io->logits, s);
-    } else if (io->logits) {
+    if (po && po->embedding) {      // packed rows: cat(h_post, raw_emb) by two strided copies
+        HIP_TRY(hipMemcpy2DAsync(po->embedding, 2 * RN_D * sizeof(float), w.n0, RN_D * sizeof(float), RN_D * sizeof(float),
+                                 po->n_total, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpy2DAsync(po->embedding + RN_D, 2 * RN_D * sizeof(float), w.n2, RN_D * sizeof(float),
+                                 RN_D * sizeof(float), po->n_total, hipMemcpyDeviceToDevice, s));
+    }
+    const bool want_logits = io->logits || (po && po->logits);
+    float* logits_rows = (po && po->logits) ? po->logits : w.logits_p;      // packed output is written in place
+    if (want_logits && run_chain(r, c->readout_chain, c->readout, w.n0, RN_D, w.n2, RN_D, logits_rows, 4)) {
+        if (io->logits) launch_unpack_nodes(r.pk, logits_rows, 4, 4, io->logits, s);
+    } else if (want_logits) {
         const float* cur = nullptr;
         int ld = 0;
         float* bufs[2] = {w.s0, w.s1};
         for (size_t i = 0; i < c->readout.size(); ++i) {
             const Lin& l = c->readout[i];
             bool last = i + 1 == c->readout.size();
-            float* dst = last ? w.logits_p : bufs[i & 1];
+            float* dst = last ? logits_rows : bufs[i & 1];
             if (i == 0) gemm(r, l, w.n0, RN_D, dst, l.out, nullptr, 0, w.n2, RN_D, RN_D);   // cat(h_post, raw_emb)
             else gemm(r, l, cur, ld, dst, l.out);
             cur = dst; ld = l.out;
         }
-        launch_unpack_nodes(r.pk, w.logits_p, 4, 4, io->logits, s);
+        if (io->logits) launch_unpack_nodes(r.pk, logits_rows, 4, 4, io->logits, s);
     }
     HIP_TRY(hipGetLastError());
     return RNAMPNN_OK;

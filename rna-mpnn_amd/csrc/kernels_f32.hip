@@ -50,6 +50,15 @@ __global__ void __launch_bounds__(1024) k_scan(const int* __restrict__ len, int 
     for (int i = lo; i < hi; ++i) { cu[i] = run; run += len[i]; }
 }
 
+__global__ void k_lengths_from_cu(const int32_t* __restrict__ cu_in, int B, int* __restrict__ len, int* __restrict__ cu) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) len[b] = cu_in[b + 1] - cu_in[b];
+    if (b <= B) cu[b] = cu_in[b] - cu_in[0];
+}
+void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s) {
+    hipLaunchKernelGGL(k_lengths_from_cu, dim3((pk.B + 256) / 256), dim3(256), 0, s, cu_seqlens, pk.B, pk.len, pk.cu);
+}
+
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s) {
     hipLaunchKernelGGL(k_lengths, dim3(pk.B), dim3(WAVE), 0, s, mask, pk.B, pk.T, pk.len);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pk.len, pk.B, pk.cu);
@@ -126,9 +135,11 @@ __global__ void k_geom(const float* __restrict__ coords, PackInfo pk, float* __r
     int b = id / pk.T, t = id - b * pk.T;
     int n = pk.len[b];
     float c[21];
-    const float* src = coords + (size_t)id * 21;
+    // padded input: residue (b, t); packed input: row cu[b] + t, and the (absent) padded residues are zeros
+    const bool have = !pk.packed_in || t < n;
+    const float* src = coords + (size_t)(pk.packed_in ? pk.cu[b] + (t < n ? t : 0) : id) * 21;
 #pragma unroll
-    for (int i = 0; i < 21; ++i) c[i] = src[i];
+    for (int i = 0; i < 21; ++i) c[i] = have ? src[i] : 0.f;
     if (t < n) {
         int p = pk.cu[b] + t;
         pk.node_b[p] = b;
@@ -198,7 +209,7 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, P
     float* drow = sm + 3 * T + grp * T;    // per-group distance row
     if (row0 < n) {
         for (int j = threadIdx.x; j < n; j += 256) {
-            const float* c = coords + ((size_t)b * T + j) * 21;
+            const float* c = coords + (size_t)(pk.packed_in ? pk.cu[b] + j : b * T + j) * 21;
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
             for (int a = 0; a < 7; ++a) { sx += c[a * 3]; sy += c[a * 3 + 1]; sz += c[a * 3 + 2]; }

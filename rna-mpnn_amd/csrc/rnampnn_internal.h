@@ -22,11 +22,13 @@ struct PackInfo {            // device arrays describing the packed batch
     int* len;                // [B]    valid length n_b
     int* cu;                 // [B+1]  exclusive prefix sum; cu[B] = N_tot
     int* node_b;             // [Nmax] RNA id of packed row p
-    int  B, T, Nmax;         // Nmax = B*T (upper bound for N_tot, known on the host)
+    int  B, T, Nmax;         // Nmax = upper bound for N_tot known on the host (B*T, or the exact total of a packed input)
+    int  packed_in;          // 1: the coords tensor is packed like the internal rows (row cu[b]+t), no padded residues
 };
 
 // ---- kernels_f32.hip -------------------------------------------------------------------
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s);
+void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s);
 void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, hipStream_t s);
 int  launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t* edge_index_out, hipStream_t s);
 void launch_edge_embed_f32(const PackInfo& pk, int k, const float* geom, const int* nbr,

@@ -55,6 +55,8 @@ SYMBOLS = {
     "rnampnn_finalize_weights": (C.c_int, [_VP, _VP]),
     "rnampnn_workspace_bytes": (_SZ, [_VP, _I32, _I32]),
     "rnampnn_forward": (C.c_int, [_VP, C.POINTER(RnaMpnnForwardIO), _VP, _SZ, _VP]),
+    "rnampnn_workspace_bytes_packed": (_SZ, [_VP, _I32, _I32]),
+    "rnampnn_forward_packed": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_mpnn_layer": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_graph_norm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP]),
     "rnampnn_rnabert": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _SZ, _VP]),

@@ -87,6 +87,32 @@ class RNAMPNN(NativeModule):
         """``RNAMPNN.embedding`` (rnampnn.py:269-278): cat(post-fusion h, raw embedding), (B, T, 256)."""
         return self._run(coords, mask, want_logits=False, want_embedding=True, T_norm=T_norm)["embedding"]
 
+    @torch.no_grad()
+    def forward_packed(self, coords_packed: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int, T_norm: int = 0,
+                       want_embedding: bool = False):
+        """Var-len form of ``forward``: ``coords_packed`` (N,7,3) holds the valid residues
+        of all RNAs back to back, ``cu_seqlens`` (B+1) int32 their exclusive prefix sum, ``max_len`` the longest
+        RNA.  Returns packed logits (N,4) [and embedding (N,256)] - identical, row for row, to the valid rows
+        of ``forward`` on the same batch padded to ``max_len`` - without moving or touching any padding."""
+        device = self._ensure()
+        c = _prep(coords_packed, device)
+        cu = _prep(cu_seqlens, device, torch.int32)
+        B, N = int(cu.numel()) - 1, int(c.shape[0])
+        logits = torch.empty(N, 4, dtype=torch.float32, device=device)
+        emb = torch.empty(N, 256, dtype=torch.float32, device=device) if want_embedding else None
+        lib = _native.lib()
+        need = int(lib.rnampnn_workspace_bytes_packed(self._handle.ptr, B, N))
+        if self._ws is None or self._ws.numel() < need + 256 or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        with torch.cuda.device(device):
+            _native.check(lib.rnampnn_forward_packed(self._handle.ptr, _ptr(c), _ptr(cu), B, N, int(max_len), int(T_norm),
+                                                     _ptr(logits), _ptr(emb), C.c_void_p(aligned),
+                                                     C.c_size_t(self._ws.numel() - (aligned - base)), _stream(device)))
+        return (logits, emb) if want_embedding else logits
+
     def forward_taps(self, coords, mask, names, tap_layer: int = 0, T_norm: int = 0):
         """Forward with intermediate tensors (parity tests): ``names`` from edge_index, raw, h0, e0,
         h_layer, e_layer, h_post, raw_emb; ``tap_layer`` is the 1-based ResMPNN layer of h_/e_layer."""

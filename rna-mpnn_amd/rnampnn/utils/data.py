@@ -33,3 +33,17 @@ def check_prefix_mask(mask: torch.Tensor) -> None:
     m = mask.detach().cpu() != 0
     if bool((m[:, 1:] & ~m[:, :-1]).any()):
         raise ValueError("mask rows must be prefixes of ones (as produced by featurize)")
+
+
+def pack_batch(coords_list: Sequence[torch.Tensor], pin: bool = True):
+    """Var-len collate: a list of (L_i,7,3) tensors -> (coords_packed (N,7,3) f32,
+    cu_seqlens (B+1) int32, max_len), in pinned host memory so ``.to(device, non_blocking=True)`` overlaps
+    the copy with compute.  No padding is materialised or copied (the padded collate moves B*T rows)."""
+    lengths = torch.tensor([int(c.shape[0]) for c in coords_list], dtype=torch.int32)
+    cu = torch.zeros(len(coords_list) + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lengths, 0)
+    packed = torch.empty((int(cu[-1]), 7, 3), dtype=torch.float32, pin_memory=pin and torch.cuda.is_available())
+    torch.cat([c.to(torch.float32) for c in coords_list], dim=0, out=packed)
+    if pin and torch.cuda.is_available():
+        cu = cu.pin_memory()
+    return packed, cu, int(lengths.max()) if len(coords_list) else 0

@@ -362,3 +362,24 @@ def test_training_loop_reduces_loss():
     logits = model(c, m)
     rec = (logits.argmax(-1).cpu() == y)[m.bool()].float().mean()
     assert rec > 0.4
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_packed_forward_equals_padded_forward(precision):
+    """F1: var-len input (valid residues only + cu_seqlens) reproduces the padded forward row for row,
+    including the phantom-edge rule of short RNAs (n-1 < k) and an unpadded longest RNA."""
+    from rnampnn.utils import synth
+    from rnampnn.utils.data import pack_batch
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    lens = [37, 5, 64, 21, 1, 48]
+    coords, mask, _ = synth.synth_batch(lens, first_index=800)
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=30, padding_len=64, num_res_mpnn_layers=3)
+    model, _ = _model(hp, state_dict_shapes(hp), precision)
+    padded = model(torch.from_numpy(coords), torch.from_numpy(mask))
+    emb_pad = model.embedding(torch.from_numpy(coords), torch.from_numpy(mask))
+    packed, cu, max_len = pack_batch([torch.from_numpy(coords[b, :n]) for b, n in enumerate(lens)])
+    assert max_len == 64 and cu.tolist() == [0, 37, 42, 106, 127, 128, 176]
+    logits, emb = model.forward_packed(packed.cuda(non_blocking=True), cu.cuda(non_blocking=True), max_len, want_embedding=True)
+    valid = torch.from_numpy(mask).bool().cuda()
+    assert torch.equal(logits, padded[valid])
+    assert torch.equal(emb, emb_pad[valid])
