@@ -493,7 +493,9 @@ static int run_bert(Run& r, const Bert& b, float* x, float* out) {
     rnampnn_ctx* c = r.c;
     for (auto& a : b.attn) {
         gemm(r, a.qkv, x, RN_D, r.w.s0, 3 * RN_D);
-        if (launch_attention_f32(r.pk, r.w.s0, b.heads, r.w.n2, r.s)) return fail(RNAMPNN_ERR_UNSUPPORTED, "head dim unsupported");
+        if (!(r.fast && launch_attention_bf16(r.pk, r.w.s0, b.heads, r.w.n2, r.s) == 0) &&
+            launch_attention_f32(r.pk, r.w.s0, b.heads, r.w.n2, r.s))
+            return fail(RNAMPNN_ERR_UNSUPPORTED, "head dim unsupported");
         gemm(r, a.out, r.w.n2, RN_D, r.w.s1, RN_D, x, RN_D);                          // x + out_proj(attn)
         launch_graph_norm_packed(r.pk, r.w.s1, nullptr, x, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s);
     }

@@ -43,3 +43,6 @@ void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s);
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
                         float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
                         const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s);
+
+// MFMA attention over valid keys (head dim 16); returns 1 when the shape is not covered (caller uses the f32 kernel)
+int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float* out, hipStream_t s);

@@ -1081,3 +1081,111 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536, s, pk, x, add, cf, h_out, j0, j1);
     else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072, s, pk, x, add, cf, h_out, j0, j1);
 }
+
+// ------------------------------------------------------------------------------------------
+// nn.MultiheadAttention over the valid keys of one RNA on MFMA (functional.py:164-168), head dim 16.
+// One workgroup per (RNA, head); wave w owns queries 32w .. 32w+31 of a 256-query sweep.
+// Transposed like everything else here: S^T[key][query] = K . Q^T puts ONE query on each lane and the
+// keys of a 32-key block on the accumulator registers, so the online softmax is in-lane (+ one
+// cross-half exchange), and the P tile is, as it stands, the B operand of O^T[d][query] += V^T . P.
+// K rows and the (k-permuted) V^T image of the whole RNA sit in LDS as ready fragments.
+__global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const float* __restrict__ qkv, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const int base = pk.cu[b];
+    const int nkb = (n + 31) / 32;
+    u32x4* Kimg = reinterpret_cast<u32x4*>(smem);              // [key][2 halves] : 8 bf16 each
+    u32x4* Vt = Kimg + (size_t)nkb * 64;                       // [kb][s][h][d 0..15] : 8 permuted keys each
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < nkb * 64; idx += 512) {          // K rows
+        const int key = idx >> 1, hh = idx & 1;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (key < n) {
+            const float* kp = qkv + (size_t)(base + key) * 384 + 128 + hd * 16 + 8 * hh;
+            f32x4 a = *reinterpret_cast<const f32x4*>(kp), c = *reinterpret_cast<const f32x4*>(kp + 4);
+            v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
+        }
+        Kimg[idx] = v;
+    }
+    for (int idx = tid; idx < nkb * 64; idx += 512) {          // V^T fragments
+        const int d = idx & 15, hh = (idx >> 4) & 1, sblk = (idx >> 5) & 1, kb = idx >> 6;
+        float vals[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+            vals[j] = key < n ? qkv[(size_t)(base + key) * 384 + 256 + hd * 16 + d] : 0.f;
+        }
+        Vt[idx] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int q0 = 32 * wave; q0 < n; q0 += 256) {
+        const int qi = q0 + r;
+        u32x4 qf = zero4;
+        if (qi < n) {
+            const float* qp = qkv + (size_t)(base + qi) * 384 + hd * 16 + 8 * h;
+            f32x4 a = *reinterpret_cast<const f32x4*>(qp), c = *reinterpret_cast<const f32x4*>(qp + 4);
+            qf = u32x4{pack2(0.25f * a[0], 0.25f * a[1]), pack2(0.25f * a[2], 0.25f * a[3]),
+                       pack2(0.25f * c[0], 0.25f * c[1]), pack2(0.25f * c[2], 0.25f * c[3])};
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float m_run = -3.0e38f, l_run = 0.f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16 sc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+            sc = mfma32(Kimg[(32 * kb + r) * 2 + h], qf, sc);                  // S^T[key][query]
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                sc[i] = key < n ? sc[i] : -3.0e38f;
+                mx = fmaxf(mx, sc[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float corr = __expf(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
+            l_run = l_run * corr + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= corr;
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const u32x4 pf = {pack2(sc[8 * sblk], sc[8 * sblk + 1]), pack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                  pack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), pack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                const u32x4 vf = r < 16 ? Vt[((kb * 2 + sblk) * 2 + h) * 16 + r] : zero4;
+                acc = mfma32(vf, pf, acc);                                       // O^T[d][query]
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (qi < n) {
+            const float inv = 1.0f / l_tot;
+            float* op = out + (size_t)(base + qi) * RN_D + hd * 16 + 4 * h;      // rows d = (i&3) + 8(i>>2) + 4h, i < 8
+            *reinterpret_cast<f32x4*>(op) = f32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+            *reinterpret_cast<f32x4*>(op + 8) = f32x4{acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+        }
+    }
+}
+
+// returns 0 when handled (head dim 16 and the RNA's K / V^T images fit LDS), 1 otherwise
+int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float* out, hipStream_t s) {
+    if (RN_D / heads != 16) return 1;
+    const int nkb = (pk.T + 31) / 32;
+    const size_t lds = (size_t)nkb * 64 * 16 * 2;
+    if (lds > 150 * 1024) return 1;
+    static size_t attr = 0;
+    if (lds > 65536 && lds > attr) {
+        (void)hipFuncSetAttribute((const void*)k_attention_bf16_hd16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(k_attention_bf16_hd16, dim3(pk.B, heads), dim3(512), lds, s, pk, qkv, out);
+    return 0;
+}
