@@ -383,3 +383,38 @@ def test_packed_forward_equals_padded_forward(precision):
     valid = torch.from_numpy(mask).bool().cuda()
     assert torch.equal(logits, padded[valid])
     assert torch.equal(emb, emb_pad[valid])
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_edge_case_shapes(precision):
+    """Degenerate inputs the reference accepts: a lone single-residue RNA (no neighbours at all), k = 1 and
+    k = 32 (kernel limits), and a batch containing an all-padding row (the reference yields NaN there through
+    its softmax over zero keys; here the row is simply zero)."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    tol = F32_LOGIT_TOL if precision == "f32" else BF16_LOGIT_TOL
+    # (a) B=1, T=n=1
+    c1, m1, _ = synth.synth_batch([1], first_index=5)
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=30, padding_len=8, num_res_mpnn_layers=2)
+    model, sd = _model(hp, state_dict_shapes(hp), precision)
+    out = model.forward_taps(torch.from_numpy(c1), torch.from_numpy(m1), ["edge_index"])
+    assert (out["edge_index"] == -1).all()
+    ref, _ = _oracle(hp, sd, c1, m1)
+    assert (out["logits"].cpu() - ref).abs().max() < tol
+    # (b) k = 1 and k = 32 on a ragged batch
+    for k in (1, 32):
+        hpk = dict(DEFAULT_HPARAMS, num_res_neighbours=k, padding_len=48, num_res_mpnn_layers=2)
+        ck, mk, _ = synth.synth_batch([40, 9, 33], first_index=60)
+        mdl, sdk = _model(hpk, state_dict_shapes(hpk), precision)
+        lg = mdl(torch.from_numpy(ck), torch.from_numpy(mk)).cpu()
+        rk, _ = _oracle(hpk, sdk, ck, mk)
+        assert torch.isfinite(lg).all() and (lg - rk).abs().max() < tol, k
+    # (c) an all-padding row inside a batch
+    c3, m3, _ = synth.synth_batch([20, 12, 7], first_index=90)
+    m3[1] = 0
+    hp3 = dict(hp, padding_len=32)
+    model3, sd3 = _model(hp3, state_dict_shapes(hp3), precision)
+    lg = model3(torch.from_numpy(c3), torch.from_numpy(m3)).cpu()
+    assert torch.isfinite(lg).all() and (lg[1] == 0).all()
+    ref0, _ = _oracle(hp3, sd3, c3[:1], m3[:1])
+    assert (lg[0] - ref0[0]).abs().max() < tol
