@@ -771,7 +771,7 @@ extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* 
     launch_pack_index(r.pk, k, edge_index, w.nbr, s);
     if (r.fast) {
         launch_pack_edges(r.pk, k, e_in, w.big, s);
-        launch_rows_to_efrag(w.big, r.ntot(), r.pk.Nmax, k, (bf16_t*)w.e, s);
+        launch_rows_to_efrag(w.big, r.ntot(), r.pk.Nmax, k, w.nbr, (bf16_t*)w.e, s);
     } else {
         launch_pack_edges(r.pk, k, e_in, (float*)w.e, s);
     }

@@ -16,7 +16,7 @@ void launch_build_embed_image(const float* w0, const float* w1, const float* b1,
 // the bf16 edge tensor is stored fragment-major (8 KiB per 32-slot block, see kernels_bf16.hip);
 // conversion to / from row-major f32 rows [(p*k + slot)][128] for taps and the stage API
 void launch_efrag_to_rows(const bf16_t* ef, const int* ntot, int nmax, int k, float* rows, hipStream_t s);
-void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, bf16_t* ef, hipStream_t s);
+void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, const int* nbr, bf16_t* ef, hipStream_t s);
 static inline size_t efrag_bytes(int nmax, int k) { int npb = k > 16 ? 1 : 32 / k; return (size_t)((nmax + npb - 1) / npb) * 8192; }
 // node-level Linear on MFMA: Y = act([X | X2] . W^T + bias) (+ res);  W bf16 [N][K] row-major
 void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,

@@ -60,6 +60,58 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// Packed-f16 activation arithmetic of the fused ResMPNN kernel: the kernel is VALU-issue
+// bound on GELU, and v_pk_*_f16 evaluates two activations per instruction with no transcendental.
+//   GELU(x) = x * Phi(x),  Phi(x) ~ clamp01(0.5 + x * q(min(x^2, S)))   (odd polynomial for Phi - 1/2; the clamp of
+//   x^2 makes the argument monotone, so beyond sqrt(S) the form saturates to exactly 0 / 1)
+// Hidden activations then stay in f16 (11-bit significand, finer than the bf16 they replace) and feed
+// v_mfma_f32_32x32x16_f16; where the result is consumed in f32 (residual, mean) the final x * Phi is a mixed-precision
+// FMA on the f32 accumulator, so only Phi itself is rounded to f16.
+#ifndef RN_PHI_DEG
+#define RN_PHI_DEG 4              // number of coefficients of q
+#endif
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ f16x2 cvt_h2(float a, float b) {          // one v_cvt_pk_f16_f32 (RNE)
+    f32x2 v = {a, b};
+    return __builtin_convertvector(v, f16x2);
+}
+__device__ __forceinline__ f16x2 h2(float v) { return f16x2{(_Float16)v, (_Float16)v}; }
+__device__ __forceinline__ f16x2 phi2(f16x2 x) {
+#if RN_PHI_DEG == 4      // max |x Phi - gelu| 3.1e-3 in exact arithmetic
+    f16x2 s = __builtin_elementwise_min(x * x, h2(9.5f));
+    f16x2 q = __builtin_elementwise_fma(s, h2(-0.00017380498f), h2(0.0048129941f));
+    q = __builtin_elementwise_fma(q, s, h2(-0.05394074f));
+    q = __builtin_elementwise_fma(q, s, h2(0.38869277f));
+#else                    // 5 coefficients in s/4 (keeps every coefficient a normal f16): 1.2e-3
+    f16x2 s = __builtin_elementwise_min(x * (x * h2(0.25f)), h2(11.5f * 0.25f));
+    f16x2 q = __builtin_elementwise_fma(s, h2(1.066712254e-05f * 256.f), h2(-0.00041787775f * 64.f));
+    q = __builtin_elementwise_fma(q, s, h2(0.00673485407f * 16.f));
+    q = __builtin_elementwise_fma(q, s, h2(-0.05988154784f * 4.f));
+    q = __builtin_elementwise_fma(q, s, h2(0.39435085475f));
+#endif
+    f16x2 p = __builtin_elementwise_fma(x, q, h2(0.5f));
+    return __builtin_elementwise_min(__builtin_elementwise_max(p, h2(0.f)), h2(1.f));
+}
+__device__ __forceinline__ unsigned gelu_h2(float a, float b) {      // two activations -> packed f16 GELU
+    f16x2 x = cvt_h2(a, b);
+    return __builtin_bit_cast(unsigned, x * phi2(x));
+}
+// a * f16(lo / hi half of hp) + c in one mixed-precision FMA (f32 result)
+__device__ __forceinline__ float fma_mix_lo(float a, f16x2 hp, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(hp), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, f16x2 hp, float c) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(hp), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // channel held by accumulator row m of a 32-row block when the output order is "natural per lane":
 // lane half h = (m>>2)&1, register i = (m&3) + 4*(m>>3)  ->  channel 32*blk + 16*h + i
 __host__ __device__ __forceinline__ int ch_nat(int blk, int m) { return 32 * blk + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
@@ -104,7 +156,8 @@ __global__ void k_build_mlp_image(const float* __restrict__ wc, int ld_wc, const
             int row = out_perm ? ch_efrag(ob, r) : 32 * ob + r;
             v = w2[(size_t)row * ld_w2 + 32 * mb + 16 * h + 8 * sp + j];
         }
-        img[id] = f2bf(v);
+        // the second Linear consumes the hidden activations, which the fused kernel keeps in f16: f16 operands
+        img[id] = which == 1 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
     }
     if (id < 128) {
         if (out_perm) {
@@ -174,28 +227,34 @@ __global__ void k_efrag_to_rows(const bf16_t* __restrict__ ef, const int* __rest
         for (int j = 0; j < 8; ++j) dst[j] = bf2f(src[j]);
     }
 }
-__global__ void k_rows_to_efrag(const float* __restrict__ rows, const int* __restrict__ ntot_p, int k, bf16_t* __restrict__ ef) {
+// row-major f32 edge rows -> fragment-major bf16.  Every slot of every block is written: padding slots and absent
+// edges (nbr < 0) as zeros - the fused kernel's unmasked loads / stores rely on that.
+__global__ void k_rows_to_efrag(const float* __restrict__ rows, const int* __restrict__ ntot_p, int k, const int* __restrict__ nbr,
+                                bf16_t* __restrict__ ef) {
     const int ntot = *ntot_p;
     const int npb = k > 16 ? 1 : 32 / k;
-    const size_t total = (size_t)ntot * k * 16;
+    const int nblocks = (ntot + npb - 1) / npb;
+    const size_t total = (size_t)nblocks * 32 * 16;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(id & 15);
-        const size_t row = id >> 4;
-        const int p = (int)(row / k), sl = (int)(row - (size_t)p * k);
-        const int blk = p / npb, r = (p - blk * npb) * k + sl;
+        const int r = (int)((id >> 4) & 31);
+        const int blk = (int)(id >> 9);
+        const int q = r / k, p = blk * npb + q, sl = r - q * k;
+        const size_t row = (size_t)p * k + sl;
+        const bool real = q < npb && p < ntot && nbr[row] >= 0;
         const int s = c8 >> 1, h = c8 & 1;
         bf16_t* dst = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
         const float* src = rows + row * RN_D + 8 * c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = f2bf(src[j]);
+        for (int j = 0; j < 8; ++j) dst[j] = real ? f2bf(src[j]) : (bf16_t)0;
     }
 }
 static unsigned conv_grid(size_t max_elems) { size_t g = (max_elems + 255) / 256; return (unsigned)(g < 8192 ? (g ? g : 1) : 8192); }
 void launch_efrag_to_rows(const bf16_t* ef, const int* ntot, int nmax, int k, float* rows, hipStream_t s) {
     hipLaunchKernelGGL(k_efrag_to_rows, dim3(conv_grid((size_t)nmax * k * 16)), dim3(256), 0, s, ef, ntot, k, rows);
 }
-void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, bf16_t* ef, hipStream_t s) {
-    hipLaunchKernelGGL(k_rows_to_efrag, dim3(conv_grid((size_t)nmax * k * 16)), dim3(256), 0, s, rows, ntot, k, ef);
+void launch_rows_to_efrag(const float* rows, const int* ntot, int nmax, int k, const int* nbr, bf16_t* ef, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_to_efrag, dim3(conv_grid((size_t)nmax * 32 * 16)), dim3(256), 0, s, rows, ntot, k, nbr, ef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,16 +313,20 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
 // (perm[s & 1], identical for every block) - exact (x 1.0, f32 accumulate) and free while the
 // kernel is VALU-issue bound.
 __device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lane, const u32x4 (&ef)[8],
-                                          const float* __restrict__ pp, const u32x4 (&qv)[8], const u32x4 (&perm)[2],
+                                          const float* __restrict__ pp, const u32x4 (&qv)[8], const u32x4* __restrict__ perm,
                                           u32x4 (&hb)[8]) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         f32x16 acc = init_vec16(pp + 32 * mb);
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc = mfma32(img[(mb * 8 + s) * 64 + lane], ef[s], acc);
-        acc = mfma32(perm[0], qv[2 * mb], acc);
-        acc = mfma32(perm[1], qv[2 * mb + 1], acc);
-        gelu_pack(acc, hb[2 * mb], hb[2 * mb + 1]);
+        acc = mfma32(perm[lane], qv[2 * mb], acc);             // routing fragments live in LDS (saves 8 VGPRs)
+        acc = mfma32(perm[64 + lane], qv[2 * mb + 1], acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            hb[2 * mb][t] = gelu_h2(acc[2 * t], acc[2 * t + 1]);
+            hb[2 * mb + 1][t] = gelu_h2(acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -275,8 +338,8 @@ __device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lan
 //            h + agg of mpnn.py:222 is taken by the graph-norm kernel that follows)
 // One wave owns one block: lanes (r, h) = (edge r of the block, k-half h).  k <= 16 packs
 // npb = 32/k residues into a block (edges of consecutive residues are contiguous in e).
-// Software pipeline per wave: the neighbour indices of the next block are fetched at the top of
-// a block, its e fragments after the first Linear; the Q gathers of a block are issued at its top.
+// Software pipeline per wave: the neighbour indices of the next block are fetched at the top of a block; its e
+// fragments and first Q rows behind the last Linear of this block (see the loop).
 #ifdef RN_STAMPS   // diagnostic build only: per-phase cycle shares of the fused kernel (never shipped enabled)
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP_ACC(idx, t0, t1) do { phase[idx] += (t1) - (t0); } while (0)
@@ -295,24 +358,51 @@ struct NodeTabs {             // per-residue parts of the first Linears (node GE
 #ifndef RN_MPNN_WAVES
 #define RN_MPNN_WAVES 12          // waves per workgroup (one workgroup per CU): 12 = 3 per SIMD (<= 168 VGPRs)
 #endif
-#ifndef RN_MPNN_PREFETCH
-#define RN_MPNN_PREFETCH 0        // 1: next block's e fragments are loaded one block ahead (+32 VGPRs)
-#endif
+#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 512 + 1024 + 1024 + 512 + 2048)
 template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
 __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
-    // LDS: [img_e 64 KiB][img_m 64 KiB][b2 of edge MLP 512 B][b2 of message MLP 512 B][per wave: P_e | P_m rows, 1 KiB]
+    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m rows, 1 KiB][128 zeros][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
-    float* lds_b2e = reinterpret_cast<float*>(smem + 131072);
-    float* lds_b2m = lds_b2e + 128;
-    const int tid = threadIdx.x;
-    float* lds_p = lds_b2m + 128 + (tid >> 6) * 256;
     constexpr int NW = RN_MPNN_WAVES;
+    const int tid = threadIdx.x;
+    float* lds_p = reinterpret_cast<float*>(smem + 131072) + (tid >> 6) * 256;
+    float* lds_zero = reinterpret_cast<float*>(smem + 131072) + NW * 256;      // the "P row" of absent edges
+    unsigned* lds_bwe = reinterpret_cast<unsigned*>(lds_zero + 128);           // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
+    unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
+    float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
+    u32x4* perm = reinterpret_cast<u32x4*>(lds_gb + 128);                       // [2][lane]: constant 0/1 routing fragments (mlp_first)
     if (DO_EDGE) for (int i = tid; i < 4096; i += NW * 64) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
     if (DO_MSG) for (int i = tid; i < 4096; i += NW * 64) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
-    if (tid < 128) { lds_b2e[tid] = DO_EDGE ? we.b2p[tid] : 0.f; lds_b2m[tid] = DO_MSG ? wm.b2p[tid] : 0.f; }
+    if (tid < 128) lds_zero[tid] = 0.f;
+    if (tid < 128) {
+        // constant routing fragments: accumulator row r of a channel block holds channel 16*sp + c16 of it
+        const int sp = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
+        const int c16 = (rr & 3) + 4 * (rr >> 3), sp_r = (rr >> 2) & 1, jstar = c16 - 8 * hh;  // element jstar of this lane's k-half
+        u32x4 pv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            pv[t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
+        perm[tid] = pv;
+    }
+    if (tid < 256) {
+        // both second-Linear biases enter through the matrix pipe: one extra MFMA whose k = 0, 1 carry b = hi + lo
+        // (bf16 split, exact to ~16 bits) against a ones column - for the edge MLP a ones column of REAL edges only,
+        // so an absent edge keeps a zero accumulator and its e row is rewritten unchanged
+        const int blk4 = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
+        const float bm = DO_MSG ? wm.b2p[32 * blk4 + rr] : 0.f;
+        const float be = DO_EDGE ? we.b2p[32 * blk4 + 16 * ((rr >> 2) & 1) + (rr & 3) + 4 * (rr >> 3)] : 0.f;
+        const unsigned mh = pack2(bm, 0.f) & 0xffffu, ml = pack2(bm - __uint_as_float(mh << 16), 0.f) & 0xffffu;
+        const unsigned eh = pack2(be, 0.f) & 0xffffu, el = pack2(be - __uint_as_float(eh << 16), 0.f) & 0xffffu;
+        lds_bwm[tid] = hh == 0 ? (mh | (ml << 16)) : 0u;
+        lds_bwe[tid] = hh == 0 ? (eh | (el << 16)) : 0u;
+        if (hh == 0) {
+            const float bs = __uint_as_float(mh << 16) + __uint_as_float(ml << 16);
+            lds_gb[32 * blk4 + rr] = bs * (float)phi2(cvt_h2(bs, bs))[0];
+        }
+    }
     __syncthreads();
 
     const int ntot = pk.cu[pk.B];
@@ -321,43 +411,42 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int zero_row = pk.Nmax;
     const int stride = gridDim.x * NW;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    // constant routing fragments: accumulator row r of a channel block holds channel 16*sp + c16 of it
-    u32x4 perm[2];
-    {
-        const int c16 = (r & 3) + 4 * (r >> 3), sp_r = (r >> 2) & 1, jstar = c16 - 8 * h;      // element jstar of this lane's k-half
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                perm[sp][t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
-    }
-    // bias of the last message Linear through the matrix pipe as well: A = [1, 1, 0, ...] (k = 0, 1 of lane half 0),
-    // B = [hi(b), lo(b), 0, ...] for output channel 32nb + r  (b = hi + lo to ~16 bits)
-    const u32x4 ones_a = {h == 0 ? 0x3F803F80u : 0u, 0u, 0u, 0u};
-    unsigned bw[4] = {0u, 0u, 0u, 0u};
-    if (DO_MSG && h == 0) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const float bf = lds_b2m[32 * nb + r];
-            const unsigned hi = pack2(bf, 0.f) & 0xffffu;
-            bw[nb] = hi | (pack2(bf - __uint_as_float(hi << 16), 0.f) << 16);
-        }
-    }
+    const int q0 = SMALLK ? r / k : 0;                // residue of the block this lane's edge slot belongs to
+    const bool slot_ok = SMALLK ? q0 < npb : r < k;
+    const int last_idx = ntot * k - 1;
+    const unsigned ones_w = h == 0 ? 0x3F803F80u : 0u;     // k = 0, 1 of lane half 0
 
     int blk = blockIdx.x * NW + wave;
     if (blk >= nblocks) return;
-    BlockLane bl = block_lane(blk, npb, k, ntot, r, nbr);
+    // Every load of the loop is unconditional (clamped addresses; padding slots of e hold zeros), so the body has no
+    // divergent branch and the compiler's s_waitcnt counts stay exact.
+#define RN_IDX(b) ({ int i_ = (b) * npb * k + r; i_ > last_idx ? last_idx : i_; })
+#define RN_GATHER(dst, table, row)                                                                  \
+    do {                                                                                            \
+        const u32x4* qp_ = reinterpret_cast<const u32x4*>((table) + (size_t)(row) * RN_D) + h;     \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) dst[s_] = qp_[2 * s_];                    \
+    } while (0)
+    int j;                                             // packed neighbour row of this lane's edge, -1: no edge
+    {
+        const int jraw = nbr[RN_IDX(blk)];
+        j = (slot_ok && blk * npb + q0 < ntot) ? jraw : -1;
+    }
     u32x4 ef[8];
+    u32x4 qe[8], qm[8];                                // gathered Q rows (bf16, 2 x 16 B per channel block)
     f32x2 pe_n = {0.f, 0.f}, pm_n = {0.f, 0.f};        // this block's P rows (2 floats per lane), !SMALLK only
     if (!SMALLK) {
         if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)blk * RN_D + 2 * lane);
         if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)blk * RN_D + 2 * lane);
     }
+    // Register-neutral software pipeline: the loads a block starts with (its e fragments and the Q rows of its first
+    // Linear) are issued one quarter-block early, behind the last Linear of the previous block, into the registers that
+    // Linear no longer needs; the Q rows of the message MLP are gathered behind the second edge Linear.
     {
         const u32x4* erp = efrag_ptr(e, blk, lane);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ef[s] = bl.ok ? erp[64 * s] : zero4;
+        for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
+        const int qrow0 = j >= 0 ? (j > zero_row ? zero_row : j) : zero_row;
+        if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow0); else RN_GATHER(qm, tab.q_m, qrow0);
     }
 #ifdef RN_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
@@ -366,92 +455,111 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         STAMP(t0);
         const int nblk = blk + stride;
         const bool has_next = nblk < nblocks;
-        const int prow = bl.ok ? bl.node : zero_row;
-        const int qrow = bl.valid ? (bl.j > zero_row ? zero_row : bl.j) : zero_row;    // phantom -> zero row
-        // gather of this block's Q_e row (bf16, 2 x 16 B per channel block) and the next block's indices
-        u32x4 qe[8], qm[8];
-        if (DO_EDGE) {
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_e + (size_t)qrow * RN_D) + h;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) qe[s] = qp[2 * s];
-        }
-        BlockLane bn = bl;
-        if (has_next) bn = block_lane(nblk, npb, k, ntot, r, nbr);
+        const int nb_c = has_next ? nblk : blk;        // the last iteration re-reads its own block (results unused)
+        const bool wr = j >= 0;                        // this lane's slot holds a real edge
+        const int prow = wr ? blk * npb + q0 : zero_row;                   // SMALLK: P row (zero row for absent edges)
+        const int qrow = wr ? (j > zero_row ? zero_row : j) : zero_row;    // phantom -> zero row
+        const int jn_raw = nbr[RN_IDX(nb_c)];          // next block's neighbour indices; consumed behind the message MLP
         if (!SMALLK) {      // one residue per block: its P rows go through a wave-private LDS slot (broadcast reads)
             if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = pe_n;
             if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = pm_n;
         }
         __builtin_amdgcn_sched_barrier(0);
 
-        u32x4 hb[8], efn[8];
+        u32x4 hb[8];
         STAMP(t1);
         if (DO_EDGE) {
-            mlp_first(img_e, lane, ef, SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : lds_p + 16 * h, qe, perm, hb);
+            const float* ppe = SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : (wr ? lds_p : lds_zero) + 16 * h;
+            mlp_first(img_e, lane, ef, ppe, qe, perm, hb);
         }
         STAMP(t2);
-#if RN_MPNN_PREFETCH
-        // Q_m gather and the next block's e fragments: in flight during the following Linear(s)
-        if (DO_MSG) {
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D) + h;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) qm[s] = qp[2 * s];
-        }
-#endif
-        {
-#if RN_MPNN_PREFETCH
-            const u32x4* erp = efrag_ptr(e, has_next ? nblk : blk, lane);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) efn[s] = (has_next && bn.ok) ? erp[64 * s] : zero4;
-#endif
-            if (!SMALLK && has_next) {
-                if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nblk * RN_D + 2 * lane);
-                if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nblk * RN_D + 2 * lane);
-            }
+        if (DO_EDGE && DO_MSG) RN_GATHER(qm, tab.q_m, qrow);       // lands during the second edge Linear
+        if (!SMALLK) {
+            if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nb_c * RN_D + 2 * lane);
+            if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nb_c * RN_D + 2 * lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(t3);
         if (DO_EDGE) {
-            // second Linear, rows in the e fragment layout: registers 0..7 of block ob <-> ef[2ob], 8..15 <-> ef[2ob+1]
-            const bool wr = bl.ok && bl.valid;
+            // second Linear, rows in the e fragment layout: registers 0..7 of block ob <-> ef[2ob], 8..15 <-> ef[2ob+1].
+            // Absent edges: zero hidden activations (zero P row, zero Q row, zero e) and no bias -> accumulator 0 ->
+            // x Phi(x) = 0: their e row is stored back unchanged, so the stores need no lane mask.
+            const u32x4 ones_b = {wr ? ones_w : 0u, 0u, 0u, 0u};
             u32x4* ewp = efrag_ptr(e, blk, lane);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
-                f32x16 acc = init_vec16(lds_b2e + 32 * ob + 16 * h);
+                const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 acc = mfma32(u32x4{lds_bwe[ob * 64 + lane], 0u, 0u, 0u}, ones_b, zacc);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32(img_e[2048 + (ob * 8 + ks) * 64 + lane], hb[ks], acc);
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(img_e[2048 + (ob * 8 + ks) * 64 + lane], hb[ks], acc);
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     u32x4 old = ef[2 * ob + sp], nw;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        nw[t] = pack2(lo_bf(old[t]) + gelu_fast(acc[8 * sp + 2 * t]),
-                                      hi_bf(old[t]) + gelu_fast(acc[8 * sp + 2 * t + 1]));
-                    if (wr) { ef[2 * ob + sp] = nw; ewp[64 * (2 * ob + sp)] = nw; }
+                    for (int t = 0; t < 4; ++t) {
+                        const float x0 = acc[8 * sp + 2 * t], x1 = acc[8 * sp + 2 * t + 1];
+                        const f16x2 ph = phi2(cvt_h2(x0, x1));
+                        nw[t] = pack2(fma_mix_lo(x0, ph, lo_bf(old[t])), fma_mix_hi(x1, ph, hi_bf(old[t])));
+                    }
+                    ef[2 * ob + sp] = nw;
+                    ewp[64 * (2 * ob + sp)] = nw;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         STAMP(t4);
-#if !RN_MPNN_PREFETCH
-        if (DO_MSG) {       // 3 waves per SIMD cover this gather; issuing it here keeps the kernel within 168 VGPRs
-            const u32x4* qp = reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qrow * RN_D) + h;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) qm[s] = qp[2 * s];
-        }
-#endif
+        const unsigned vmask = (unsigned)(__ballot(wr) & 0xffffffffull);   // bit r = edge r is real
         if (DO_MSG) {
-            mlp_first(img_m, lane, ef, SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : lds_p + 128 + 16 * h, qm, perm, hb);
-            STAMP(t5);
-            const unsigned vmask = (unsigned)(__ballot(bl.ok && bl.valid) & 0xffffffffull);   // bit r = edge r is real
+            const float* ppm = SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : (wr ? lds_p + 128 : lds_zero) + 16 * h;
+            mlp_first(img_m, lane, ef, ppm, qm, perm, hb);
+        }
+        STAMP(t5);
+        int jn;
+        {   // e and the first Q rows of the next block: in flight during the last Linear
+            const u32x4* erp = efrag_ptr(e, nb_c, lane);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
+            jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
+            const int qrow_n = jn >= 0 ? (jn > zero_row ? zero_row : jn) : zero_row;
+            if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow_n); else RN_GATHER(qm, tab.q_m, qrow_n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (DO_MSG) {
             // last Linear un-transposed: rows = edges of the block (registers), columns = channels 32nb + r
+            const int cnt_all = __popc(vmask);
+            const float inv_all = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
+            const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = mfma32(ones_a, u32x4{bw[nb], 0u, 0u, 0u}, zacc);          // bias
+                f32x16 acc = mfma32(ones_a, u32x4{lds_bwm[nb * 64 + lane], 0u, 0u, 0u}, zacc);          // bias
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32(hb[ks], img_m[2048 + (nb * 8 + ks) * 64 + lane], acc);
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(hb[ks], img_m[2048 + (nb * 8 + ks) * 64 + lane], acc);
+                if (!SMALLK && !MSGOUT) {
+                    // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly
+                    // (zero hidden activations) and are taken out again
+                    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = gelu_fast(acc[i]);
+                    for (int i = 0; i < 16; i += 4) {
+                        const f16x2 pa = phi2(cvt_h2(acc[i], acc[i + 1])), pb = phi2(cvt_h2(acc[i + 2], acc[i + 3]));
+                        s0 = fma_mix_lo(acc[i], pa, s0);
+                        s1 = fma_mix_hi(acc[i + 1], pa, s1);
+                        s0 = fma_mix_lo(acc[i + 2], pb, s0);
+                        s1 = fma_mix_hi(acc[i + 3], pb, s1);
+                    }
+                    float sum = s0 + s1;
+                    sum += __shfl_xor(sum, 32, 64);
+                    // both lane halves hold the total: the duplicate store of half 1 saves a divergent branch
+                    agg[(size_t)blk * RN_D + 32 * nb + r] = (sum - (float)(32 - cnt_all) * lds_gb[32 * nb + r]) * inv_all;
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f16x2 ph = phi2(cvt_h2(acc[i], acc[i + 1]));
+                    acc[i] *= (float)ph[0];
+                    acc[i + 1] *= (float)ph[1];
+                }
                 if (MSGOUT) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -485,18 +593,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #endif
         if (!has_next) break;
         blk = nblk;
-        bl = bn;
-#if RN_MPNN_PREFETCH
-#pragma unroll
-        for (int s = 0; s < 8; ++s) ef[s] = efn[s];
-#else
-        {
-            const u32x4* erp = efrag_ptr(e, blk, lane);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) ef[s] = bl.ok ? erp[64 * s] : zero4;
-        }
-#endif
+        j = jn;
     }
+#undef RN_GATHER
+#undef RN_IDX
 #ifdef RN_STAMPS
     if (tab.dbg && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(tab.dbg + i, phase[i]);
@@ -522,7 +622,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
-    size_t lds = 131072 + 1024 + RN_MPNN_WAVES * 1024;
+    size_t lds = RN_MPNN_LDS;
     NodeTabs tab{p_e, q_e, p_m, q_m, nullptr};
 #ifdef RN_STAMPS
     static unsigned long long* dbg = nullptr;
@@ -535,7 +635,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     do {                                                                                                       \
         static bool done = false;                                                                              \
         if (!done) {                                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024 + RN_MPNN_WAVES * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, RN_MPNN_LDS); \
             done = true;                                                                                       \
         }                                                                                                      \
         hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(RN_MPNN_WAVES * 64), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
@@ -636,15 +736,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
             f32x16 acc = init_vec16(b1p + 32 * ob + 16 * h);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc = mfma32(img[(4 * EMB_KS + ob * 8 + ks) * 64 + lane], hb[ks], acc);
-            if (bl.ok) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    u32x4 nw;
+            for (int sp = 0; sp < 2; ++sp) {        // padding slots of the block and absent edges are stored as zeros
+                u32x4 nw;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        nw[t] = bl.valid ? pack2(gelu_fast(acc[8 * sp + 2 * t]), gelu_fast(acc[8 * sp + 2 * t + 1])) : 0u;
-                    ewp[64 * (2 * ob + sp)] = nw;
-                }
+                for (int t = 0; t < 4; ++t)
+                    nw[t] = bl.valid ? pack2(gelu_fast(acc[8 * sp + 2 * t]), gelu_fast(acc[8 * sp + 2 * t + 1])) : 0u;
+                ewp[64 * (2 * ob + sp)] = nw;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
