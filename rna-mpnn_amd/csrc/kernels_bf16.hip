@@ -97,6 +97,42 @@ __device__ __forceinline__ unsigned gelu_h2(float a, float b) {      // two acti
     f16x2 x = cvt_h2(a, b);
     return __builtin_bit_cast(unsigned, x * phi2(x));
 }
+// Four activations at a time: the two packed chains are independent, so the compiler interleaves them and the
+// one-wait-state hazard between dependent VOP3P instructions (an s_nop 0 = 4 issue cycles each) disappears.
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ f16x4 h4(float v) { return f16x4{(_Float16)v, (_Float16)v, (_Float16)v, (_Float16)v}; }
+__device__ __forceinline__ f16x4 cvt_h4(float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    return __builtin_convertvector(v, f16x4);
+}
+__device__ __forceinline__ f16x4 phi4(f16x4 x) {
+#if RN_PHI_DEG == 4
+    f16x4 s = __builtin_elementwise_min(x * x, h4(9.5f));
+    f16x4 q = __builtin_elementwise_fma(s, h4(-0.00017380498f), h4(0.0048129941f));
+    q = __builtin_elementwise_fma(q, s, h4(-0.05394074f));
+    q = __builtin_elementwise_fma(q, s, h4(0.38869277f));
+#else
+    f16x4 s = __builtin_elementwise_min(x * (x * h4(0.25f)), h4(11.5f * 0.25f));
+    f16x4 q = __builtin_elementwise_fma(s, h4(1.066712254e-05f * 256.f), h4(-0.00041787775f * 64.f));
+    q = __builtin_elementwise_fma(q, s, h4(0.00673485407f * 16.f));
+    q = __builtin_elementwise_fma(q, s, h4(-0.05988154784f * 4.f));
+    q = __builtin_elementwise_fma(q, s, h4(0.39435085475f));
+#endif
+    f16x4 p = __builtin_elementwise_fma(x, q, h4(0.5f));
+    return __builtin_elementwise_min(__builtin_elementwise_max(p, h4(0.f)), h4(1.f));
+}
+__device__ __forceinline__ f16x2 lo2(f16x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f16x2 hi2(f16x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+// scheduling fence between the channel-block steps of a Linear (RN_SB_INNER=0: let the compiler interleave the MFMAs
+// of step i+1 with the activation arithmetic of step i; needs a second accumulator tile)
+#ifndef RN_SB_INNER
+#define RN_SB_INNER 1
+#endif
+#if RN_SB_INNER
+#define RN_INNER_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RN_INNER_FENCE() do { } while (0)
+#endif
 // a * f16(lo / hi half of hp) + c in one mixed-precision FMA (f32 result)
 __device__ __forceinline__ float fma_mix_lo(float a, f16x2 hp, float c) {
     float d;
@@ -305,32 +341,6 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
     }
 }
 
-// First Linear (+GELU) of an e-MLP: hb[2mb + s'] = bf16(GELU(P[i] + Q[j] + Wc . e)), channel blocks mb.
-// P row (f32, the same address for every lane of a half: a broadcast LDS read) initialises the
-// accumulator.  The gathered Q row (bf16, fetched in the e-fragment layout: qv[s] = channels 16s+8h..)
-// is added by the MATRIX pipe, not the VALU: two extra MFMAs per channel block whose A operand is
-// the constant 0/1 matrix that routes channel 16s+8h+j to the accumulator row holding it
-// (perm[s & 1], identical for every block) - exact (x 1.0, f32 accumulate) and free while the
-// kernel is VALU-issue bound.
-__device__ __forceinline__ void mlp_first(const u32x4* __restrict__ img, int lane, const u32x4 (&ef)[8],
-                                          const float* __restrict__ pp, const u32x4 (&qv)[8], const u32x4* __restrict__ perm,
-                                          u32x4 (&hb)[8]) {
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        f32x16 acc = init_vec16(pp + 32 * mb);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = mfma32(img[(mb * 8 + s) * 64 + lane], ef[s], acc);
-        acc = mfma32(perm[lane], qv[2 * mb], acc);             // routing fragments live in LDS (saves 8 VGPRs)
-        acc = mfma32(perm[64 + lane], qv[2 * mb + 1], acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            hb[2 * mb][t] = gelu_h2(acc[2 * t], acc[2 * t + 1]);
-            hb[2 * mb + 1][t] = gelu_h2(acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Fused ResMPNN step on 32-edge blocks (mpnn.py:154-265), bf16 MFMA:
 //   DO_EDGE: e <- e + MLP_e(P_e[i] + Q_e[j] + e Wc_e)   (edge update of the previous layer)
@@ -356,13 +366,20 @@ struct NodeTabs {             // per-residue parts of the first Linears (node GE
 };
 
 #ifndef RN_MPNN_WAVES
-#define RN_MPNN_WAVES 12          // waves per workgroup (one workgroup per CU): 12 = 3 per SIMD (<= 168 VGPRs)
+#define RN_MPNN_WAVES 8           // waves per workgroup (one workgroup per CU): 2 per SIMD, <= 256 VGPRs each
 #endif
 #define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 512 + 1024 + 1024 + 512 + 2048)
+// Execution shape.  A block runs 16 "stages" - 4 channel blocks x {edge Linear 1, edge Linear 2, message Linear 1,
+// message Linear 2} - each a chain of 9-10 dependent MFMAs followed by the activation arithmetic of its 32x32 tile
+// (packed-f16 VALU).  Inside a wave the two are serial; they overlap ACROSS the two waves of a SIMD (separate pipes),
+// provided a chain runs at matrix-pipe rate.  Hence the one rule of the loop: every LDS operand of a chain (its 8
+// weight fragments, the P-row accumulator init or the bias word) is requested one stage early, right behind the
+// previous chain, and lands while that stage's VALU work runs (wf / cin / bword below).  HBM operands are requested a
+// quarter block early in the same spirit (see the loop).
 template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
 __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
-    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m rows, 1 KiB][128 zeros][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B]
+    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m rows, 1 KiB][128 zeros][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
@@ -373,24 +390,26 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     unsigned* lds_bwe = reinterpret_cast<unsigned*>(lds_zero + 128);           // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
     unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
     float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
-    u32x4* perm = reinterpret_cast<u32x4*>(lds_gb + 128);                       // [2][lane]: constant 0/1 routing fragments (mlp_first)
+    u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_gb + 128);                   // [2][lane]: constant 0/1 routing fragments
     if (DO_EDGE) for (int i = tid; i < 4096; i += NW * 64) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
     if (DO_MSG) for (int i = tid; i < 4096; i += NW * 64) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
     if (tid < 128) lds_zero[tid] = 0.f;
     if (tid < 128) {
-        // constant routing fragments: accumulator row r of a channel block holds channel 16*sp + c16 of it
+        // The gathered Q row (bf16, fetched in the e-fragment layout: q[s] = channels 16s+8h..) is added by the MATRIX
+        // pipe: two extra MFMAs per channel block whose A operand is the constant 0/1 matrix that routes channel
+        // 16s+8h+j to the accumulator row holding it (identical for every block; exact: x 1.0, f32 accumulate).
         const int sp = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
         const int c16 = (rr & 3) + 4 * (rr >> 3), sp_r = (rr >> 2) & 1, jstar = c16 - 8 * hh;  // element jstar of this lane's k-half
         u32x4 pv;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             pv[t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
-        perm[tid] = pv;
+        lds_perm[tid] = pv;
     }
     if (tid < 256) {
-        // both second-Linear biases enter through the matrix pipe: one extra MFMA whose k = 0, 1 carry b = hi + lo
-        // (bf16 split, exact to ~16 bits) against a ones column - for the edge MLP a ones column of REAL edges only,
-        // so an absent edge keeps a zero accumulator and its e row is rewritten unchanged
+        // both second-Linear biases enter through the matrix pipe as well: one extra MFMA whose k = 0, 1 carry
+        // b = hi + lo (bf16 split, exact to ~16 bits) against a ones column - for the edge MLP a ones column of REAL
+        // edges only, so an absent edge keeps a zero accumulator and its e row is rewritten unchanged
         const int blk4 = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
         const float bm = DO_MSG ? wm.b2p[32 * blk4 + rr] : 0.f;
         const float be = DO_EDGE ? we.b2p[32 * blk4 + 16 * ((rr >> 2) & 1) + (rr & 3) + 4 * (rr >> 3)] : 0.f;
@@ -415,9 +434,13 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     const bool slot_ok = SMALLK ? q0 < npb : r < k;
     const int last_idx = ntot * k - 1;
     const unsigned ones_w = h == 0 ? 0x3F803F80u : 0u;     // k = 0, 1 of lane half 0
+    const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
 
     int blk = blockIdx.x * NW + wave;
     if (blk >= nblocks) return;
+#ifdef RN_STAGGER      // experiment: start the second wave of every SIMD (waves NW/2..) later, so the pair does not run in lockstep
+    if (wave >= NW / 2) __builtin_amdgcn_s_sleep(RN_STAGGER);
+#endif
     // Every load of the loop is unconditional (clamped addresses; padding slots of e hold zeros), so the body has no
     // divergent branch and the compiler's s_waitcnt counts stay exact.
 #define RN_IDX(b) ({ int i_ = (b) * npb * k + r; i_ > last_idx ? last_idx : i_; })
@@ -426,6 +449,23 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         const u32x4* qp_ = reinterpret_cast<const u32x4*>((table) + (size_t)(row) * RN_D) + h;     \
         _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) dst[s_] = qp_[2 * s_];                    \
     } while (0)
+    // stage operands requested one stage early
+    u32x4 wf[8];                                       // the chain's 8 weight fragments
+    f32x16 cin;                                        // first Linears: accumulator init = P row of the residue
+    unsigned bword = 0u;                               // second Linears: bias word
+#define RN_PRE_FIRST(img, mb, pp)                                                                   \
+    do {                                                                                            \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) wf[s_] = (img)[((mb) * 8 + s_) * 64 + lane]; \
+        cin = init_vec16((pp) + 32 * (mb));                                                         \
+    } while (0)
+#define RN_PRE_SECOND(img, ob, bwtab)                                                               \
+    do {                                                                                            \
+        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) wf[s_] = (img)[2048 + ((ob) * 8 + s_) * 64 + lane]; \
+        bword = (bwtab)[(ob) * 64 + lane];                                                          \
+    } while (0)
+    // P-row source of a lane: the residue's row (SMALLK: straight from HBM; else the wave's LDS slot), zeros for an absent edge
+#define RN_PP(tabp, slot, real, row) (SMALLK ? (tabp) + (size_t)(row) * RN_D + 16 * h : ((real) ? lds_p + (slot) : lds_zero) + 16 * h)
+
     int j;                                             // packed neighbour row of this lane's edge, -1: no edge
     {
         const int jraw = nbr[RN_IDX(blk)];
@@ -433,20 +473,20 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     }
     u32x4 ef[8];
     u32x4 qe[8], qm[8];                                // gathered Q rows (bf16, 2 x 16 B per channel block)
-    f32x2 pe_n = {0.f, 0.f}, pm_n = {0.f, 0.f};        // this block's P rows (2 floats per lane), !SMALLK only
-    if (!SMALLK) {
-        if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)blk * RN_D + 2 * lane);
-        if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)blk * RN_D + 2 * lane);
-    }
-    // Register-neutral software pipeline: the loads a block starts with (its e fragments and the Q rows of its first
-    // Linear) are issued one quarter-block early, behind the last Linear of the previous block, into the registers that
-    // Linear no longer needs; the Q rows of the message MLP are gathered behind the second edge Linear.
+    f32x2 pe_n = {0.f, 0.f}, pm_n = {0.f, 0.f};        // next block's P rows (2 floats per lane), !SMALLK only
     {
         const u32x4* erp = efrag_ptr(e, blk, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
         const int qrow0 = j >= 0 ? (j > zero_row ? zero_row : j) : zero_row;
         if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow0); else RN_GATHER(qm, tab.q_m, qrow0);
+        if (!SMALLK) {
+            if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)blk * RN_D + 2 * lane);
+            if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)blk * RN_D + 2 * lane);
+        }
+        const int prow0 = j >= 0 ? blk * npb + q0 : zero_row;
+        if (DO_EDGE) RN_PRE_FIRST(img_e, 0, RN_PP(tab.p_e, 0, j >= 0, prow0));
+        else RN_PRE_FIRST(img_m, 0, RN_PP(tab.p_m, 128, j >= 0, prow0));
     }
 #ifdef RN_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
@@ -460,26 +500,39 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         const int prow = wr ? blk * npb + q0 : zero_row;                   // SMALLK: P row (zero row for absent edges)
         const int qrow = wr ? (j > zero_row ? zero_row : j) : zero_row;    // phantom -> zero row
         const int jn_raw = nbr[RN_IDX(nb_c)];          // next block's neighbour indices; consumed behind the message MLP
-        if (!SMALLK) {      // one residue per block: its P rows go through a wave-private LDS slot (broadcast reads)
-            if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = pe_n;
-            if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = pm_n;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        u32x4 hb[8];
-        STAMP(t1);
-        if (DO_EDGE) {
-            const float* ppe = SMALLK ? tab.p_e + (size_t)prow * RN_D + 16 * h : (wr ? lds_p : lds_zero) + 16 * h;
-            mlp_first(img_e, lane, ef, ppe, qe, perm, hb);
-        }
-        STAMP(t2);
-        if (DO_EDGE && DO_MSG) RN_GATHER(qm, tab.q_m, qrow);       // lands during the second edge Linear
-        if (!SMALLK) {
+        if (!SMALLK) {                                 // next block's P rows: to LDS behind the message MLP
             if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nb_c * RN_D + 2 * lane);
             if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nb_c * RN_D + 2 * lane);
         }
+        u32x4 hb[8];
+        STAMP(t1);
+        if (DO_EDGE) {
+            // first edge Linear (+GELU): hb[2mb + s'] = f16(GELU(P[i] + Q[j] + Wc . e)), channel blocks mb
+            const float* ppe = RN_PP(tab.p_e, 0, wr, prow);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x16 acc = cin;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = mfma32(wf[s], ef[s], acc);
+                acc = mfma32(perm0, qe[2 * mb], acc);
+                acc = mfma32(perm1, qe[2 * mb + 1], acc);
+                if (mb < 3) RN_PRE_FIRST(img_e, mb + 1, ppe); else RN_PRE_SECOND(img_e, 0, lds_bwe);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+                    const f16x4 g = x * phi4(x);
+                    hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
+                    hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        STAMP(t2);
+        if (DO_EDGE && DO_MSG) RN_GATHER(qm, tab.q_m, qrow);       // lands during the second edge Linear
         __builtin_amdgcn_sched_barrier(0);
         STAMP(t3);
+        const float* ppm = RN_PP(tab.p_m, 128, wr, prow);
         if (DO_EDGE) {
             // second Linear, rows in the e fragment layout: registers 0..7 of block ob <-> ef[2ob], 8..15 <-> ef[2ob+1].
             // Absent edges: zero hidden activations (zero P row, zero Q row, zero e) and no bias -> accumulator 0 ->
@@ -489,17 +542,22 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = mfma32(u32x4{lds_bwe[ob * 64 + lane], 0u, 0u, 0u}, ones_b, zacc);
+                f32x16 acc = mfma32(u32x4{bword, 0u, 0u, 0u}, ones_b, zacc);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(img_e[2048 + (ob * 8 + ks) * 64 + lane], hb[ks], acc);
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(wf[ks], hb[ks], acc);
+                if (ob < 3) RN_PRE_SECOND(img_e, ob + 1, lds_bwe);
+                else if (DO_MSG) RN_PRE_FIRST(img_m, 0, ppm);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp) {
                     u32x4 old = ef[2 * ob + sp], nw;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float x0 = acc[8 * sp + 2 * t], x1 = acc[8 * sp + 2 * t + 1];
-                        const f16x2 ph = phi2(cvt_h2(x0, x1));
-                        nw[t] = pack2(fma_mix_lo(x0, ph, lo_bf(old[t])), fma_mix_hi(x1, ph, hi_bf(old[t])));
+                    for (int t = 0; t < 4; t += 2) {
+                        const f16x4 ph = phi4(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
+                        nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), lo_bf(old[t])),
+                                      fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), hi_bf(old[t])));
+                        nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), lo_bf(old[t + 1])),
+                                          fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), hi_bf(old[t + 1])));
                     }
                     ef[2 * ob + sp] = nw;
                     ewp[64 * (2 * ob + sp)] = nw;
@@ -510,20 +568,47 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         STAMP(t4);
         const unsigned vmask = (unsigned)(__ballot(wr) & 0xffffffffull);   // bit r = edge r is real
         if (DO_MSG) {
-            const float* ppm = SMALLK ? tab.p_m + (size_t)prow * RN_D + 16 * h : (wr ? lds_p + 128 : lds_zero) + 16 * h;
-            mlp_first(img_m, lane, ef, ppm, qm, perm, hb);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x16 acc = cin;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = mfma32(wf[s], ef[s], acc);
+                acc = mfma32(perm0, qm[2 * mb], acc);
+                acc = mfma32(perm1, qm[2 * mb + 1], acc);
+                if (mb < 3) RN_PRE_FIRST(img_m, mb + 1, ppm); else RN_PRE_SECOND(img_m, 0, lds_bwm);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+                    const f16x4 g = x * phi4(x);
+                    hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
+                    hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         STAMP(t5);
-        int jn;
-        {   // e and the first Q rows of the next block: in flight during the last Linear
+        // e, the first Q rows and the P rows of the next block: in flight / staged during the last Linear
+        const int jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
+        const int prow_n = jn >= 0 ? nb_c * npb + q0 : zero_row;
+        {
             const u32x4* erp = efrag_ptr(e, nb_c, lane);
 #pragma unroll
             for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
-            jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
             const int qrow_n = jn >= 0 ? (jn > zero_row ? zero_row : jn) : zero_row;
             if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow_n); else RN_GATHER(qm, tab.q_m, qrow_n);
+            if (!SMALLK) {
+                if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = pe_n;
+                if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = pm_n;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+#define RN_PRE_NEXT_BLOCK()                                                                          \
+        do {                                                                                         \
+            if (DO_EDGE) RN_PRE_FIRST(img_e, 0, RN_PP(tab.p_e, 0, jn >= 0, prow_n));                \
+            else RN_PRE_FIRST(img_m, 0, RN_PP(tab.p_m, 128, jn >= 0, prow_n));                      \
+        } while (0)
+        if (!DO_MSG) RN_PRE_NEXT_BLOCK();
         if (DO_MSG) {
             // last Linear un-transposed: rows = edges of the block (registers), columns = channels 32nb + r
             const int cnt_all = __popc(vmask);
@@ -532,16 +617,19 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = mfma32(ones_a, u32x4{lds_bwm[nb * 64 + lane], 0u, 0u, 0u}, zacc);          // bias
+                f32x16 acc = mfma32(ones_a, u32x4{bword, 0u, 0u, 0u}, zacc);          // bias
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(hb[ks], img_m[2048 + (nb * 8 + ks) * 64 + lane], acc);
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(hb[ks], wf[ks], acc);
+                if (nb < 3) RN_PRE_SECOND(img_m, nb + 1, lds_bwm); else RN_PRE_NEXT_BLOCK();
+                __builtin_amdgcn_sched_barrier(0);
                 if (!SMALLK && !MSGOUT) {
                     // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly
                     // (zero hidden activations) and are taken out again
                     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                     for (int i = 0; i < 16; i += 4) {
-                        const f16x2 pa = phi2(cvt_h2(acc[i], acc[i + 1])), pb = phi2(cvt_h2(acc[i + 2], acc[i + 3]));
+                        const f16x4 p4 = phi4(cvt_h4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]));
+                        const f16x2 pa = lo2(p4), pb = hi2(p4);
                         s0 = fma_mix_lo(acc[i], pa, s0);
                         s1 = fma_mix_hi(acc[i + 1], pa, s1);
                         s0 = fma_mix_lo(acc[i + 2], pb, s0);
@@ -595,6 +683,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         blk = nblk;
         j = jn;
     }
+#undef RN_PRE_NEXT_BLOCK
+#undef RN_PP
+#undef RN_PRE_SECOND
+#undef RN_PRE_FIRST
 #undef RN_GATHER
 #undef RN_IDX
 #ifdef RN_STAMPS
