@@ -19,6 +19,7 @@
 // ds_read_b128); a 512-thread workgroup per CU loads them once and then walks 32-edge blocks.
 #include "kernels_bf16.h"
 #include <cstdio>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -123,16 +124,20 @@ __device__ __forceinline__ f16x4 phi4(f16x4 x) {
 }
 __device__ __forceinline__ f16x2 lo2(f16x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f16x2 hi2(f16x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
-// scheduling fence between the channel-block steps of a Linear (RN_SB_INNER=0: let the compiler interleave the MFMAs
-// of step i+1 with the activation arithmetic of step i; needs a second accumulator tile)
-#ifndef RN_SB_INNER
-#define RN_SB_INNER 1
-#endif
-#if RN_SB_INNER
-#define RN_INNER_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define RN_INNER_FENCE() do { } while (0)
-#endif
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+// x as a (hi, lo) pair of bf16 in one word (hi in the low half): x = hi + lo to ~16 bits.  Operand of the k = 2 MFMAs that
+// add a per-row constant (bias, P row) to an accumulator tile.
+__device__ __forceinline__ unsigned split_word(float x) {
+    const unsigned hi = pack2(x, 0.f) & 0xffffu;
+    return hi | (pack2(x - __uint_as_float(hi << 16), 0.f) << 16);
+}
 // a * f16(lo / hi half of hp) + c in one mixed-precision FMA (f32 result)
 __device__ __forceinline__ float fma_mix_lo(float a, f16x2 hp, float c) {
     float d;
@@ -348,19 +353,15 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
 //            h + agg of mpnn.py:222 is taken by the graph-norm kernel that follows)
 // One wave owns one block: lanes (r, h) = (edge r of the block, k-half h).  k <= 16 packs
 // npb = 32/k residues into a block (edges of consecutive residues are contiguous in e).
-// Software pipeline per wave: the neighbour indices of the next block are fetched at the top of a block; its e
-// fragments and first Q rows behind the last Linear of this block (see the loop).
 #ifdef RN_STAMPS   // diagnostic build only: per-phase cycle shares of the fused kernel (never shipped enabled)
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_ACC(idx, t0, t1) do { phase[idx] += (t1) - (t0); } while (0)
 #else
 #define STAMP(var) do { } while (0)
-#define STAMP_ACC(idx, t0, t1) do { } while (0)
 #endif
-struct NodeTabs {             // per-residue parts of the first Linears (node GEMM outputs)
-    const float* p_e;         // [N+1][128] f32   h.Wa_e^T + b1_e
+struct NodeTabs {             // per-residue parts of the first Linears (k_node_update outputs)
+    const unsigned* p_e;      // [N+1][128] words: P = h.Wa_e^T + b1_e as (hi, lo) bf16 pairs, word 32mb + m <-> channel ch_nat(mb, m)
     const bf16_t* q_e;        // [N+1][128] bf16  h.Wb_e^T         (row N = zeros)
-    const float* p_m;
+    const unsigned* p_m;
     const bf16_t* q_m;
     unsigned long long* dbg;  // RN_STAMPS diagnostic buffer (null otherwise)
 };
@@ -368,32 +369,38 @@ struct NodeTabs {             // per-residue parts of the first Linears (node GE
 #ifndef RN_MPNN_WAVES
 #define RN_MPNN_WAVES 8           // waves per workgroup (one workgroup per CU): 2 per SIMD, <= 256 VGPRs each
 #endif
-#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 512 + 1024 + 1024 + 512 + 2048)
-// Execution shape.  A block runs 16 "stages" - 4 channel blocks x {edge Linear 1, edge Linear 2, message Linear 1,
-// message Linear 2} - each a chain of 9-10 dependent MFMAs followed by the activation arithmetic of its 32x32 tile
-// (packed-f16 VALU).  Inside a wave the two are serial; they overlap ACROSS the two waves of a SIMD (separate pipes),
-// provided a chain runs at matrix-pipe rate.  Hence the one rule of the loop: every LDS operand of a chain (its 8
-// weight fragments, the P-row accumulator init or the bias word) is requested one stage early, right behind the
-// previous chain, and lands while that stage's VALU work runs (wf / cin / bword below).  HBM operands are requested a
-// quarter block early in the same spirit (see the loop).
+#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 1024 + 1024 + 512 + 2048)
+// Execution shape.  A block runs 16 chains - 4 channel blocks x {edge Linear 1, edge Linear 2, message Linear 1,
+// message Linear 2} - of 9-11 dependent MFMAs on a 32x32 accumulator tile, each followed by the activation
+// arithmetic of that tile ("epilogue": packed-f16 VALU).  A wave issues in order, so the two only overlap if they are
+// interleaved in program order: slot c of the loop issues chain c into one tile while the epilogue of chain c-1 runs
+// out of the other tile, one quarter tile after every second MFMA (an MFMA holds the matrix pipe for 32 cycles and
+// the vector issue for 8 of them; the ~20 VALU instructions between two MFMAs ride in that shadow).  The slot order
+// is pinned with scheduling fences.  Data dependencies between chains exist only where one Linear feeds the next
+// (hb, the updated e): there the consumer's k-steps 6 and 7 - the ones the last epilogue quarter produces - come
+// last in the chain.  The chain of the NEXT block's first channel block runs against the last epilogue of this one.
+//   No operand of a chain waits on LDS or HBM at issue: weight fragment s of the next chain is requested right
+// after MFMA s of this one has consumed its register (wf ring), every accumulator starts from the literal 0 - the
+// P row of the residue (first Linears) and the bias (second Linears) enter as a k = 2 MFMA of (hi, lo) bf16 words
+// against a ones column of the REAL edges (so an absent edge keeps a zero accumulator everywhere: its hidden
+// activations are 0, its e row is rewritten unchanged, its message row is GELU(bias)) - and the e fragments and
+// Q rows of the next block are requested during the last four chains of this one.
 template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
 __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
-    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m rows, 1 KiB][128 zeros][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB]
+    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m words, 1 KiB][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
     constexpr int NW = RN_MPNN_WAVES;
     const int tid = threadIdx.x;
-    float* lds_p = reinterpret_cast<float*>(smem + 131072) + (tid >> 6) * 256;
-    float* lds_zero = reinterpret_cast<float*>(smem + 131072) + NW * 256;      // the "P row" of absent edges
-    unsigned* lds_bwe = reinterpret_cast<unsigned*>(lds_zero + 128);           // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
+    unsigned* lds_p = reinterpret_cast<unsigned*>(smem + 131072) + (tid >> 6) * 256;
+    unsigned* lds_bwe = reinterpret_cast<unsigned*>(smem + 131072) + NW * 256;  // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
     unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
     float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
     u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_gb + 128);                   // [2][lane]: constant 0/1 routing fragments
     if (DO_EDGE) for (int i = tid; i < 4096; i += NW * 64) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
     if (DO_MSG) for (int i = tid; i < 4096; i += NW * 64) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
-    if (tid < 128) lds_zero[tid] = 0.f;
     if (tid < 128) {
         // The gathered Q row (bf16, fetched in the e-fragment layout: q[s] = channels 16s+8h..) is added by the MATRIX
         // pipe: two extra MFMAs per channel block whose A operand is the constant 0/1 matrix that routes channel
@@ -407,18 +414,14 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         lds_perm[tid] = pv;
     }
     if (tid < 256) {
-        // both second-Linear biases enter through the matrix pipe as well: one extra MFMA whose k = 0, 1 carry
-        // b = hi + lo (bf16 split, exact to ~16 bits) against a ones column - for the edge MLP a ones column of REAL
-        // edges only, so an absent edge keeps a zero accumulator and its e row is rewritten unchanged
         const int blk4 = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
         const float bm = DO_MSG ? wm.b2p[32 * blk4 + rr] : 0.f;
         const float be = DO_EDGE ? we.b2p[32 * blk4 + 16 * ((rr >> 2) & 1) + (rr & 3) + 4 * (rr >> 3)] : 0.f;
-        const unsigned mh = pack2(bm, 0.f) & 0xffffu, ml = pack2(bm - __uint_as_float(mh << 16), 0.f) & 0xffffu;
-        const unsigned eh = pack2(be, 0.f) & 0xffffu, el = pack2(be - __uint_as_float(eh << 16), 0.f) & 0xffffu;
-        lds_bwm[tid] = hh == 0 ? (mh | (ml << 16)) : 0u;
-        lds_bwe[tid] = hh == 0 ? (eh | (el << 16)) : 0u;
+        const unsigned mw = split_word(bm), ew = split_word(be);
+        lds_bwm[tid] = hh == 0 ? mw : 0u;
+        lds_bwe[tid] = hh == 0 ? ew : 0u;
         if (hh == 0) {
-            const float bs = __uint_as_float(mh << 16) + __uint_as_float(ml << 16);
+            const float bs = __uint_as_float(mw << 16) + __uint_as_float(mw & 0xffff0000u);
             lds_gb[32 * blk4 + rr] = bs * (float)phi2(cvt_h2(bs, bs))[0];
         }
     }
@@ -429,270 +432,320 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     const int nblocks = (ntot + npb - 1) / npb;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int zero_row = pk.Nmax;
-    const int stride = gridDim.x * NW;
     const int q0 = SMALLK ? r / k : 0;                // residue of the block this lane's edge slot belongs to
     const bool slot_ok = SMALLK ? q0 < npb : r < k;
     const int last_idx = ntot * k - 1;
     const unsigned ones_w = h == 0 ? 0x3F803F80u : 0u;     // k = 0, 1 of lane half 0
     const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
+    const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
+    unsigned bwn = 0u;                                 // bias word of the NEXT chain (second Linears), requested mid-chain
+    float gbv = 0.f;                                   // GELU(bias) of the channel whose mean is being formed
 
-    int blk = blockIdx.x * NW + wave;
-    if (blk >= nblocks) return;
-#ifdef RN_STAGGER      // experiment: start the second wave of every SIMD (waves NW/2..) later, so the pair does not run in lockstep
-    if (wave >= NW / 2) __builtin_amdgcn_s_sleep(RN_STAGGER);
+    // XCD-aware block mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  XCD x
+    // owns a CONTIGUOUS eighth of the residues (whole RNAs, mostly), so the Q / P rows its gathers touch (2 MB instead of
+    // the full 16 MB tables) stay resident in that L2 next to the streaming e blocks; within the eighth the waves stride.
+    int blk, blk_end, stride;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (nblocks + 7) >> 3, x = blockIdx.x & 7;
+        blk_end = min(nblocks, (x + 1) * chunk);
+        stride = (gridDim.x >> 3) * NW;
+        blk = x * chunk + (blockIdx.x >> 3) * NW + wave;
+    } else {
+        blk_end = nblocks; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
+    }
+    if (blk >= blk_end) return;
+#ifdef RN_STAGGER      // experiment: spread the waves of a CU over the block period so their HBM request bursts do not coincide
+    for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(RN_STAGGER);
 #endif
-    // Every load of the loop is unconditional (clamped addresses; padding slots of e hold zeros), so the body has no
-    // divergent branch and the compiler's s_waitcnt counts stay exact.
-#define RN_IDX(b) ({ int i_ = (b) * npb * k + r; i_ > last_idx ? last_idx : i_; })
-#define RN_GATHER(dst, table, row)                                                                  \
-    do {                                                                                            \
-        const u32x4* qp_ = reinterpret_cast<const u32x4*>((table) + (size_t)(row) * RN_D) + h;     \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) dst[s_] = qp_[2 * s_];                    \
-    } while (0)
-    // stage operands requested one stage early
-    u32x4 wf[8];                                       // the chain's 8 weight fragments
-    f32x16 cin;                                        // first Linears: accumulator init = P row of the residue
-    unsigned bword = 0u;                               // second Linears: bias word
-#define RN_PRE_FIRST(img, mb, pp)                                                                   \
-    do {                                                                                            \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) wf[s_] = (img)[((mb) * 8 + s_) * 64 + lane]; \
-        cin = init_vec16((pp) + 32 * (mb));                                                         \
-    } while (0)
-#define RN_PRE_SECOND(img, ob, bwtab)                                                               \
-    do {                                                                                            \
-        _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) wf[s_] = (img)[2048 + ((ob) * 8 + s_) * 64 + lane]; \
-        bword = (bwtab)[(ob) * 64 + lane];                                                          \
-    } while (0)
-    // P-row source of a lane: the residue's row (SMALLK: straight from HBM; else the wave's LDS slot), zeros for an absent edge
-#define RN_PP(tabp, slot, real, row) (SMALLK ? (tabp) + (size_t)(row) * RN_D + 16 * h : ((real) ? lds_p + (slot) : lds_zero) + 16 * h)
 
+    // chain sequence of a block: c = 0..3 edge Linear 1, 4..7 edge Linear 2, 8..11 message Linear 1, 12..15 message Linear 2
+    constexpr int C_FIRST = DO_EDGE ? 0 : 8, C_LAST = DO_MSG ? 15 : 7;
+#define RN_FRAG(c, s) (((c) < 8 ? img_e : img_m)[(((c) >> 2) & 1) * 2048 + (((c) & 3) * 8 + (s)) * 64 + lane])
+#define RN_NEXT(c) ((c) == C_LAST ? C_FIRST : (c) + 1)
+#define RN_IDX(b) ({ int i_ = (b) * npb * k + r; i_ > last_idx ? last_idx : i_; })
+#define RN_QROW(jj) ((jj) >= 0 ? ((jj) > zero_row ? zero_row : (jj)) : zero_row)
+#define RN_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    u32x4 ef[8], q[8], hb[8], wf[8];                  // q: gathered Q rows of the MLP whose first Linear runs next
+    f32x16 tA, tB;                                     // accumulator tiles: chain c runs in (c & 1 ? tB : tA)
+    u32x4 pwe = {0u, 0u, 0u, 0u}, pwm = {0u, 0u, 0u, 0u};      // !SMALLK: P words of the block's residue, [mb]
     int j;                                             // packed neighbour row of this lane's edge, -1: no edge
-    {
-        const int jraw = nbr[RN_IDX(blk)];
-        j = (slot_ok && blk * npb + q0 < ntot) ? jraw : -1;
-    }
-    u32x4 ef[8];
-    u32x4 qe[8], qm[8];                                // gathered Q rows (bf16, 2 x 16 B per channel block)
-    f32x2 pe_n = {0.f, 0.f}, pm_n = {0.f, 0.f};        // next block's P rows (2 floats per lane), !SMALLK only
-    {
-        const u32x4* erp = efrag_ptr(e, blk, lane);
+    // ---- block state: everything a block needs from HBM (addresses clamped, loads unconditional)
+    auto load_index = [&](int b) { const int jr = nbr[RN_IDX(b)]; return (slot_ok && b * npb + q0 < ntot) ? jr : -1; };
+    auto load_e = [&](int b, int s) { ef[s] = efrag_ptr(e, b, lane)[64 * s]; };
+    auto gather_q = [&](u32x4 (&dst)[8], const bf16_t* table, int row, int s) {
+        dst[s] = (reinterpret_cast<const u32x4*>(table + (size_t)row * RN_D) + h)[2 * s];
+    };
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 pn_e = {0u, 0u}, pn_m = {0u, 0u};
+    auto load_p = [&](int b) {                         // !SMALLK: the residue's P words (coalesced 512 B rows), requested early ...
+        if (SMALLK) return;
+        if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + 2 * lane);
+        if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + 2 * lane);
+    };
+    auto stage_p = [&]() {                             // ... through the wave's LDS slot ...
+        if (SMALLK) return;
+        if (DO_EDGE) *reinterpret_cast<u32x2*>(lds_p + 2 * lane) = pn_e;
+        if (DO_MSG) *reinterpret_cast<u32x2*>(lds_p + 128 + 2 * lane) = pn_m;
+    };
+    auto fetch_p = [&]() {                             // ... back as this lane's four words per MLP
+        if (SMALLK) return;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
-        const int qrow0 = j >= 0 ? (j > zero_row ? zero_row : j) : zero_row;
-        if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow0); else RN_GATHER(qm, tab.q_m, qrow0);
-        if (!SMALLK) {
-            if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)blk * RN_D + 2 * lane);
-            if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)blk * RN_D + 2 * lane);
+        for (int mb = 0; mb < 4; ++mb) {
+            if (DO_EDGE) pwe[mb] = h == 0 ? lds_p[32 * mb + r] : 0u;
+            if (DO_MSG) pwm[mb] = h == 0 ? lds_p[128 + 32 * mb + r] : 0u;
         }
-        const int prow0 = j >= 0 ? blk * npb + q0 : zero_row;
-        if (DO_EDGE) RN_PRE_FIRST(img_e, 0, RN_PP(tab.p_e, 0, j >= 0, prow0));
-        else RN_PRE_FIRST(img_m, 0, RN_PP(tab.p_m, 128, j >= 0, prow0));
+    };
+    // ---- one MFMA of chain c (compile-time c, i), accumulating in T
+    //   first Linears  (11): [P words x ones(real edges)] [W . e, k-steps 0..7] [routing x Q, 2]
+    //   second Linears ( 9): [bias words x ones]          [W . hidden, k-steps 0..7]
+    unsigned onesb = 0u;                               // ones column of this block's real edges (B operand, k = 0, 1)
+    auto inject_p = [&](f32x16& T, const unsigned* ptab, unsigned pw, int mb) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!SMALLK) { T = mfma32(u32x4{pw, 0u, 0u, 0u}, u32x4{onesb, 0u, 0u, 0u}, z); return; }
+        // several residues per block: k-pair 4h + jj of group g carries residue g + 4h + jj against the indicator of its edges
+        T = z;
+        for (int g = 0; g < npb; g += 8) {
+            u32x4 aw, bwv;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int qq = g + 4 * h + jj, node = blk * npb + qq;
+                aw[jj] = (qq < npb && node < ntot) ? ptab[(size_t)node * RN_D + 32 * mb + r] : 0u;
+                bwv[jj] = (j >= 0 && q0 == qq) ? 0x3F803F80u : 0u;
+            }
+            T = mfma32(aw, bwv, T);
+        }
+    };
+    auto chain_step = [&](auto cc, auto ii, f32x16& T) {
+        constexpr int c = decltype(cc)::value, i = decltype(ii)::value;
+        constexpr int kind = c >> 2, cb = c & 3;       // kind 0: E1, 1: E2, 2: M1, 3: M2
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (i == 0) {
+            if constexpr (kind == 0) inject_p(T, tab.p_e, pwe[cb], cb);
+            else if constexpr (kind == 2) inject_p(T, tab.p_m, pwm[cb], cb);
+            else if constexpr (kind == 1) T = mfma32(u32x4{bwn, 0u, 0u, 0u}, u32x4{onesb, 0u, 0u, 0u}, z);
+            else T = mfma32(ones_a, u32x4{bwn, 0u, 0u, 0u}, z);
+        } else if constexpr (i <= 8) {
+            constexpr int s = i - 1;
+            if constexpr (kind == 0 || kind == 2) T = mfma32(wf[s], ef[s], T);
+            else if constexpr (kind == 1) T = mfma32h(wf[s], hb[s], T);
+            else T = mfma32h(hb[s], wf[s], T);
+            wf[s] = RN_FRAG(RN_NEXT(c), s);            // the register is free again: request the next chain's fragment
+            if constexpr (i == 4) {
+                constexpr int cn = RN_NEXT(c), kn = cn >> 2;
+                if constexpr (kn == 1) bwn = lds_bwe[(cn & 3) * 64 + lane];
+                else if constexpr (kn == 3) bwn = lds_bwm[(cn & 3) * 64 + lane];
+            }
+        } else {
+            T = mfma32(i == 9 ? perm0 : perm1, q[2 * cb + (i - 9)], T);
+        }
+    };
+    // ---- the epilogue of chain c in GRANULES of ~8 vector instructions (one rides behind each MFMA of the next chain).
+    // Quarter v = accumulator registers 4v..4v+3 (two packed-f16 pairs, evaluated side by side so that no VOP3P result
+    // is consumed by the very next instruction); a quarter is 2 granules for the first Linears
+    // (A: x, x^2, clamp, first Horner step; B: rest of Phi, x Phi -> hb) and 3 for the second ones (C: the f32 tail -
+    // residual add and bf16 repack of e, or the running sum of the mean).  g* = context of the block the chain belongs to.
+    static_assert(RN_PHI_DEG == 4, "the granule form of the epilogue implements the 4-coefficient Phi");
+    float s0 = 0.f, s1 = 0.f;
+    f16x4 gx = h4(0.f), gs = h4(0.f), gq = h4(0.f);    // state carried between the granules of a quarter
+    auto epi_granule = [&](auto cc, auto gg, f32x16& T, int gblk, unsigned gvmask, float gcntf, float ginv) {
+        constexpr int c = decltype(cc)::value, g = decltype(gg)::value;
+        constexpr int kind = c >> 2, cb = c & 3;
+        constexpr int gpq = (kind & 1) ? 3 : 2;        // granules per quarter
+        constexpr int v = g / gpq, ph = g % gpq;
+        if constexpr (ph == 0) {
+            gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
+            gs = __builtin_elementwise_min(gx * gx, h4(9.5f));
+            gq = __builtin_elementwise_fma(gs, h4(-0.00017380498f), h4(0.0048129941f));
+        } else if constexpr (ph == 1) {
+            gq = __builtin_elementwise_fma(gq, gs, h4(-0.05394074f));
+            gq = __builtin_elementwise_fma(gq, gs, h4(0.38869277f));
+            const f16x4 pp = __builtin_elementwise_fma(gx, gq, h4(0.5f));
+            gq = __builtin_elementwise_min(__builtin_elementwise_max(pp, h4(0.f)), h4(1.f));      // gq now holds Phi
+            if constexpr (kind == 0 || kind == 2) {    // hidden activations -> f16 operand fragments of the second Linear
+                const f16x4 gv = gx * gq;
+                hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
+                hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
+            }
+        } else if constexpr (kind == 1) {              // e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
+            constexpr int sp = v >> 1, t = 2 * (v & 1);
+            const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
+            ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
+            ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
+            if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
+        } else if constexpr (!SMALLK && !MSGOUT) {     // mean over the real edges of the residue
+            // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly and are taken out again
+            if constexpr (v == 0) { s0 = 0.f; s1 = 0.f; gbv = lds_gb[32 * cb + r]; }
+            s0 = fma_mix_lo(T[4 * v], lo2(gq), s0);
+            s1 = fma_mix_hi(T[4 * v + 1], lo2(gq), s1);
+            s0 = fma_mix_lo(T[4 * v + 2], hi2(gq), s0);
+            s1 = fma_mix_hi(T[4 * v + 3], hi2(gq), s1);
+            if constexpr (v == 3) {
+                float sum = s0 + s1;
+                sum += __shfl_xor(sum, 32, 64);
+                // both lane halves hold the total: the duplicate store of half 1 saves a divergent branch
+                agg[(size_t)gblk * RN_D + 32 * cb + r] = (sum - gcntf * gbv) * ginv;
+            }
+        } else {                                       // several residues per block / per-edge message output
+            T[4 * v] *= (float)gq[0]; T[4 * v + 1] *= (float)gq[1]; T[4 * v + 2] *= (float)gq[2]; T[4 * v + 3] *= (float)gq[3];
+            if constexpr (v == 3) {                    // ... the whole activated tile at once
+                if (MSGOUT) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int er = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const int node = gblk * npb + er / k;
+                        if (er < npb * k && node < ntot)
+                            msg_out[((size_t)gblk * npb * k + er) * RN_D + 32 * cb + r] = T[i] * (float)((gvmask >> er) & 1u);
+                    }
+                }
+                for (int q1 = 0; q1 < npb; ++q1) {
+                    const int node = gblk * npb + q1;
+                    if (node >= ntot) break;
+                    const unsigned seg = SMALLK ? (gvmask & (((1u << k) - 1u) << (q1 * k))) : gvmask;
+                    const unsigned segh = seg >> (4 * h);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        sum = fmaf(T[i], (float)((segh >> ((i & 3) + 8 * (i >> 2))) & 1u), sum);
+                    sum += __shfl_xor(sum, 32, 64);
+                    const int cnt = __popc(seg);
+                    if (h == 0) agg[(size_t)node * RN_D + 32 * cb + r] = sum / (float)(cnt > 0 ? cnt : 1);
+                }
+            }
+        }
+    };
+#define RN_NGRAN(c) ((((c) >> 2) & 1) ? 12 : 8)
+
+    // ---- prologue: state of the first block, fragments of its first chain
+    j = load_index(blk);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) load_e(blk, s);
+    {
+        const int qr = RN_QROW(j);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) gather_q(q, DO_EDGE ? tab.q_e : tab.q_m, qr, s);
     }
+    load_p(blk);
+    stage_p();
+    fetch_p();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wf[s] = RN_FRAG(C_FIRST, s);
+    onesb = j >= 0 ? ones_w : 0u;
+
+    // slot c: chain c against the epilogue of chain cprev (the one before it in the sequence; for the first chain of a
+    // block that is the last chain of the previous block, whose context g* is still in place)
+    int gblk = blk; unsigned gvmask = 0u; float gcntf = 0.f, ginv = 0.f;
+#define RN_TILE(c) (((c) & 1) ? tB : tA)
+// MFMA order of a chain: the k-steps fed by the epilogue running beside it come last (BOUNDARY slots: the consumer of a
+// Linear boundary; a first Linear then issues its two routing MFMAs before k-steps 6 and 7)
+#define RN_SLOT(c, cprev, WITH_EPI, EXTRA)                                                                     \
+    do {                                                                                                       \
+        constexpr int nst_ = (((c) >> 2) & 1) ? 9 : 11;                                                        \
+        constexpr bool bnd_ = (WITH_EPI) && ((c) >> 2) != ((cprev) >> 2) && ((cprev) >> 2) != 3;               \
+        constexpr int ngr_ = (WITH_EPI) ? RN_NGRAN(cprev) : 0;                                                 \
+        constexpr int nfree_ = bnd_ ? nst_ - 2 : nst_;      /* MFMAs the granules are spread behind */         \
+        static_for<nst_>([&](auto ii) {                                                                        \
+            constexpr int p_ = decltype(ii)::value;                                                            \
+            constexpr int i_ = (bnd_ && nst_ == 11) ? (p_ <= 6 ? p_ : p_ <= 8 ? p_ + 2 : p_ - 2) : p_;         \
+            chain_step(std::integral_constant<int, (c)>{}, std::integral_constant<int, i_>{}, RN_TILE(c));     \
+            EXTRA(i_);                                                                                         \
+            RN_FENCE();                                                                                        \
+            if constexpr (ngr_ > 0 && p_ < nfree_) {                                                           \
+                constexpr int g0_ = p_ * ngr_ / nfree_, g1_ = (p_ + 1) * ngr_ / nfree_;                        \
+                static_for<g1_ - g0_>([&](auto dg) {                                                           \
+                    epi_granule(std::integral_constant<int, (cprev)>{}, std::integral_constant<int, g0_ + decltype(dg)::value>{}, RN_TILE(cprev), gblk, gvmask, gcntf, ginv); \
+                });                                                                                            \
+                RN_FENCE();                                                                                    \
+            }                                                                                                  \
+        });                                                                                                    \
+    } while (0)
+#define RN_NOEXTRA(i) do { } while (0)
+
+    RN_SLOT(C_FIRST, C_FIRST, false, RN_NOEXTRA);      // first chain of the first block: nothing to overlap with yet
 #ifdef RN_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
 #endif
     while (true) {
         STAMP(t0);
         const int nblk = blk + stride;
-        const bool has_next = nblk < nblocks;
+        const bool has_next = nblk < blk_end;
         const int nb_c = has_next ? nblk : blk;        // the last iteration re-reads its own block (results unused)
-        const bool wr = j >= 0;                        // this lane's slot holds a real edge
-        const int prow = wr ? blk * npb + q0 : zero_row;                   // SMALLK: P row (zero row for absent edges)
-        const int qrow = wr ? (j > zero_row ? zero_row : j) : zero_row;    // phantom -> zero row
-        const int jn_raw = nbr[RN_IDX(nb_c)];          // next block's neighbour indices; consumed behind the message MLP
-        if (!SMALLK) {                                 // next block's P rows: to LDS behind the message MLP
-            if (DO_EDGE) pe_n = *reinterpret_cast<const f32x2*>(tab.p_e + (size_t)nb_c * RN_D + 2 * lane);
-            if (DO_MSG) pm_n = *reinterpret_cast<const f32x2*>(tab.p_m + (size_t)nb_c * RN_D + 2 * lane);
-        }
-        u32x4 hb[8];
-        STAMP(t1);
-        if (DO_EDGE) {
-            // first edge Linear (+GELU): hb[2mb + s'] = f16(GELU(P[i] + Q[j] + Wc . e)), channel blocks mb
-            const float* ppe = RN_PP(tab.p_e, 0, wr, prow);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x16 acc = cin;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc = mfma32(wf[s], ef[s], acc);
-                acc = mfma32(perm0, qe[2 * mb], acc);
-                acc = mfma32(perm1, qe[2 * mb + 1], acc);
-                if (mb < 3) RN_PRE_FIRST(img_e, mb + 1, ppe); else RN_PRE_SECOND(img_e, 0, lds_bwe);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-                    const f16x4 g = x * phi4(x);
-                    hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
-                    hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        STAMP(t2);
-        if (DO_EDGE && DO_MSG) RN_GATHER(qm, tab.q_m, qrow);       // lands during the second edge Linear
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(t3);
-        const float* ppm = RN_PP(tab.p_m, 128, wr, prow);
-        if (DO_EDGE) {
-            // second Linear, rows in the e fragment layout: registers 0..7 of block ob <-> ef[2ob], 8..15 <-> ef[2ob+1].
-            // Absent edges: zero hidden activations (zero P row, zero Q row, zero e) and no bias -> accumulator 0 ->
-            // x Phi(x) = 0: their e row is stored back unchanged, so the stores need no lane mask.
-            const u32x4 ones_b = {wr ? ones_w : 0u, 0u, 0u, 0u};
-            u32x4* ewp = efrag_ptr(e, blk, lane);
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
-                const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = mfma32(u32x4{bword, 0u, 0u, 0u}, ones_b, zacc);
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(wf[ks], hb[ks], acc);
-                if (ob < 3) RN_PRE_SECOND(img_e, ob + 1, lds_bwe);
-                else if (DO_MSG) RN_PRE_FIRST(img_m, 0, ppm);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    u32x4 old = ef[2 * ob + sp], nw;
-#pragma unroll
-                    for (int t = 0; t < 4; t += 2) {
-                        const f16x4 ph = phi4(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
-                        nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), lo_bf(old[t])),
-                                      fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), hi_bf(old[t])));
-                        nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), lo_bf(old[t + 1])),
-                                          fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), hi_bf(old[t + 1])));
-                    }
-                    ef[2 * ob + sp] = nw;
-                    ewp[64 * (2 * ob + sp)] = nw;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        STAMP(t4);
-        const unsigned vmask = (unsigned)(__ballot(wr) & 0xffffffffull);   // bit r = edge r is real
-        if (DO_MSG) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                f32x16 acc = cin;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc = mfma32(wf[s], ef[s], acc);
-                acc = mfma32(perm0, qm[2 * mb], acc);
-                acc = mfma32(perm1, qm[2 * mb + 1], acc);
-                if (mb < 3) RN_PRE_FIRST(img_m, mb + 1, ppm); else RN_PRE_SECOND(img_m, 0, lds_bwm);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-                    const f16x4 g = x * phi4(x);
-                    hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
-                    hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        STAMP(t5);
-        // e, the first Q rows and the P rows of the next block: in flight / staged during the last Linear
-        const int jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
-        const int prow_n = jn >= 0 ? nb_c * npb + q0 : zero_row;
+        const int jn_raw = nbr[RN_IDX(nb_c)];          // next block's neighbour indices and P words; consumed behind the message MLP
+        load_p(nb_c);
         {
-            const u32x4* erp = efrag_ptr(e, nb_c, lane);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) ef[s] = erp[64 * s];
-            const int qrow_n = jn >= 0 ? (jn > zero_row ? zero_row : jn) : zero_row;
-            if (DO_EDGE) RN_GATHER(qe, tab.q_e, qrow_n); else RN_GATHER(qm, tab.q_m, qrow_n);
-            if (!SMALLK) {
-                if (DO_EDGE) *reinterpret_cast<f32x2*>(lds_p + 2 * lane) = pe_n;
-                if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 128 + 2 * lane) = pm_n;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#define RN_PRE_NEXT_BLOCK()                                                                          \
-        do {                                                                                         \
-            if (DO_EDGE) RN_PRE_FIRST(img_e, 0, RN_PP(tab.p_e, 0, jn >= 0, prow_n));                \
-            else RN_PRE_FIRST(img_m, 0, RN_PP(tab.p_m, 128, jn >= 0, prow_n));                      \
-        } while (0)
-        if (!DO_MSG) RN_PRE_NEXT_BLOCK();
-        if (DO_MSG) {
-            // last Linear un-transposed: rows = edges of the block (registers), columns = channels 32nb + r
+            const unsigned vmask = (unsigned)(__ballot(j >= 0) & 0xffffffffull);   // bit r = edge r is real
             const int cnt_all = __popc(vmask);
-            const float inv_all = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
-            const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 acc = mfma32(ones_a, u32x4{bword, 0u, 0u, 0u}, zacc);          // bias
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32h(hb[ks], wf[ks], acc);
-                if (nb < 3) RN_PRE_SECOND(img_m, nb + 1, lds_bwm); else RN_PRE_NEXT_BLOCK();
-                __builtin_amdgcn_sched_barrier(0);
-                if (!SMALLK && !MSGOUT) {
-                    // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly
-                    // (zero hidden activations) and are taken out again
-                    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 16; i += 4) {
-                        const f16x4 p4 = phi4(cvt_h4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]));
-                        const f16x2 pa = lo2(p4), pb = hi2(p4);
-                        s0 = fma_mix_lo(acc[i], pa, s0);
-                        s1 = fma_mix_hi(acc[i + 1], pa, s1);
-                        s0 = fma_mix_lo(acc[i + 2], pb, s0);
-                        s1 = fma_mix_hi(acc[i + 3], pb, s1);
-                    }
-                    float sum = s0 + s1;
-                    sum += __shfl_xor(sum, 32, 64);
-                    // both lane halves hold the total: the duplicate store of half 1 saves a divergent branch
-                    agg[(size_t)blk * RN_D + 32 * nb + r] = (sum - (float)(32 - cnt_all) * lds_gb[32 * nb + r]) * inv_all;
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const f16x2 ph = phi2(cvt_h2(acc[i], acc[i + 1]));
-                    acc[i] *= (float)ph[0];
-                    acc[i + 1] *= (float)ph[1];
-                }
-                if (MSGOUT) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int er = (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const int node = blk * npb + er / k;
-                        if (er < npb * k && node < ntot)
-                            msg_out[((size_t)blk * npb * k + er) * RN_D + 32 * nb + r] = acc[i] * (float)((vmask >> er) & 1u);
-                    }
-                }
-                for (int q = 0; q < (SMALLK ? npb : 1); ++q) {
-                    const int node = blk * npb + q;
-                    if (node >= ntot) break;
-                    const unsigned seg = SMALLK ? (vmask & (((1u << k) - 1u) << (q * k))) : vmask;
-                    const unsigned segh = seg >> (4 * h);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        sum = fmaf(acc[i], (float)((segh >> ((i & 3) + 8 * (i >> 2))) & 1u), sum);
-                    sum += __shfl_xor(sum, 32, 64);
-                    const int cnt = __popc(seg);
-                    if (h == 0) agg[(size_t)node * RN_D + 32 * nb + r] = sum / (float)(cnt > 0 ? cnt : 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            gblk = blk; gvmask = vmask; gcntf = (float)(32 - cnt_all);
+            ginv = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
         }
-        STAMP(t6);
-        STAMP_ACC(0, t0, t1); STAMP_ACC(1, t1, t2); STAMP_ACC(2, t2, t3); STAMP_ACC(3, t3, t4);
-        STAMP_ACC(4, t4, t5); STAMP_ACC(5, t5, t6); STAMP_ACC(6, t0, t6);
-#ifdef RN_STAMPS
-        phase[7] += 1;
-#endif
+        int jn = -1;
+        // requests for the next block ride behind the MFMAs of the last four chains of this one
+#define RN_EXTRA_N(cc, i) do { if constexpr ((cc) == 0 && (i) == 0) { jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1; stage_p(); } \
+                               if constexpr ((i) == 1 || (i) == 2) load_e(nb_c, 2 * (cc) + (i) - 1);               \
+                               if constexpr ((i) == 3 || (i) == 4) gather_q(q, DO_EDGE ? tab.q_e : tab.q_m, RN_QROW(jn), 2 * (cc) + (i) - 3); } while (0)
+#define RN_EXTRA_N0(i) RN_EXTRA_N(0, i)
+#define RN_EXTRA_N1(i) RN_EXTRA_N(1, i)
+#define RN_EXTRA_N2(i) RN_EXTRA_N(2, i)
+#define RN_EXTRA_N3(i) RN_EXTRA_N(3, i)
+        // ... and the Q rows of this block's message MLP behind the first chain of the second edge Linear
+#define RN_EXTRA_QM(i) do { if constexpr ((i) >= 1 && (i) <= 8 && DO_MSG) gather_q(q, tab.q_m, RN_QROW(j), (i) - 1); } while (0)
+        if constexpr (DO_EDGE) {
+            RN_SLOT(1, 0, true, RN_NOEXTRA); RN_SLOT(2, 1, true, RN_NOEXTRA); RN_SLOT(3, 2, true, RN_NOEXTRA);
+            STAMP(t1);
+            RN_SLOT(4, 3, true, RN_EXTRA_QM); RN_SLOT(5, 4, true, RN_NOEXTRA); RN_SLOT(6, 5, true, RN_NOEXTRA); RN_SLOT(7, 6, true, RN_NOEXTRA);
+            STAMP(t2);
+        }
+        if constexpr (DO_EDGE && DO_MSG) RN_SLOT(8, 7, true, RN_NOEXTRA);
+        if constexpr (DO_MSG) {
+            RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_NOEXTRA);
+            STAMP(t3);
+            RN_SLOT(12, 11, true, RN_EXTRA_N0); RN_SLOT(13, 12, true, RN_EXTRA_N1);
+            STAMP(t4);
+            RN_SLOT(14, 13, true, RN_EXTRA_N2); RN_SLOT(15, 14, true, RN_EXTRA_N3);
+            STAMP(t5);
+        } else {
+            // edge update only (stand-alone API): the last epilogue rewrites e, so the next block's state cannot be requested early
+            static_for<RN_NGRAN(7)>([&](auto gg) { epi_granule(std::integral_constant<int, 7>{}, gg, RN_TILE(7), gblk, gvmask, gcntf, ginv); });
+            RN_FENCE();
+            jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
+            stage_p();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { load_e(nb_c, s); gather_q(q, tab.q_e, RN_QROW(jn), s); }
+        }
         if (!has_next) break;
+        fetch_p();
         blk = nblk;
         j = jn;
+        onesb = j >= 0 ? ones_w : 0u;
+        RN_FENCE();
+        if constexpr (DO_MSG) RN_SLOT(C_FIRST, 15, true, RN_NOEXTRA);      // first chain of the next block || last epilogue of this one
+        else RN_SLOT(C_FIRST, C_FIRST, false, RN_NOEXTRA);
+#ifdef RN_STAMPS
+        STAMP(t6);
+        phase[0] += t1 - t0; phase[1] += t2 - t1; phase[2] += t3 - t2; phase[3] += t4 - t3; phase[4] += t5 - t4; phase[5] += t6 - t5;
+        phase[6] += t6 - t0; phase[7] += 1;
+#endif
     }
-#undef RN_PRE_NEXT_BLOCK
-#undef RN_PP
-#undef RN_PRE_SECOND
-#undef RN_PRE_FIRST
-#undef RN_GATHER
-#undef RN_IDX
 #ifdef RN_STAMPS
     if (tab.dbg && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(tab.dbg + i, phase[i]);
 #endif
+    if constexpr (DO_MSG) static_for<RN_NGRAN(15)>([&](auto gg) { epi_granule(std::integral_constant<int, 15>{}, gg, RN_TILE(15), gblk, gvmask, gcntf, ginv); });
+#undef RN_EXTRA_QM
+#undef RN_EXTRA_N3
+#undef RN_EXTRA_N2
+#undef RN_EXTRA_N1
+#undef RN_EXTRA_N0
+#undef RN_EXTRA_N
+#undef RN_NOEXTRA
+#undef RN_SLOT
+#undef RN_NGRAN
+#undef RN_TILE
+#undef RN_FENCE
+#undef RN_QROW
+#undef RN_IDX
+#undef RN_NEXT
+#undef RN_FRAG
 }
 
 static int num_cus() {
@@ -712,10 +765,11 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
     int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
+    if (grid >= 8) grid = (grid + 7) & ~7;            // a multiple of 8 switches the kernel to its XCD-aware block mapping
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
     size_t lds = RN_MPNN_LDS;
-    NodeTabs tab{p_e, q_e, p_m, q_m, nullptr};
+    NodeTabs tab{reinterpret_cast<const unsigned*>(p_e), q_e, reinterpret_cast<const unsigned*>(p_m), q_m, nullptr};
 #ifdef RN_STAMPS
     static unsigned long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc((void**)&dbg, 64);
@@ -742,7 +796,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(hst, dbg, 64, hipMemcpyDeviceToHost);
     if (hst[7]) {
-        fprintf(stderr, "[stamps e=%d m=%d] blocks %llu cycles/block: top %.0f E1 %.0f issue %.0f E2 %.0f M1 %.0f M2 %.0f total %.0f\n",
+        fprintf(stderr, "[stamps e=%d m=%d] blocks %llu cycles/block: slots 1-3 %.0f | 4-7 %.0f | 8-11 %.0f | 12-13 %.0f | 14-15 %.0f | next 0 %.0f | total %.0f\n",
                 (int)do_edge, (int)do_msg, hst[7], (double)hst[0] / hst[7], (double)hst[1] / hst[7], (double)hst[2] / hst[7],
                 (double)hst[3] / hst[7], (double)hst[4] / hst[7], (double)hst[5] / hst[7], (double)hst[6] / hst[7]);
     }
@@ -1174,7 +1228,7 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
     }
 }
 
-struct PqJob { const bf16_t* img; const float* bias; float* p; bf16_t* q; };   // img: [8 ob][8 ks][64][8]; ob<4 -> P rows, >=4 -> Q rows
+struct PqJob { const bf16_t* img; const float* bias; float* p; bf16_t* q; };   // img: [8 ob][8 ks][64][8]; ob<4 -> P rows (stored as split-bf16 words), >=4 -> Q rows
 
 template <int NJOBS>
 __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
@@ -1228,10 +1282,13 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
             if (ok) {
                 if (ob < 4) {
-                    float* dst = jbq.p + (size_t)row * RN_D + 32 * ob + 16 * h;
+                    // P leaves as (hi, lo) bf16 words in accumulator-row order: word 32ob + m <-> channel ch_nat(ob, m),
+                    // m = (i & 3) + 4h + 8(i >> 2) for register i - the A operand of the fused kernel's P-injection MFMA
+                    unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + (size_t)row * RN_D + 32 * ob + 4 * h;
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
-                        *reinterpret_cast<f32x4*>(dst + 4 * v) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+                        *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
+                                                                        split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
                 } else {
                     u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + (size_t)row * RN_D + 32 * (ob - 4) + 16 * h);
                     dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};

@@ -14,7 +14,7 @@ import torch  # noqa: F401  - FIRST: the process must use ONE HIP runtime (the o
 #                librnampnn_hip.so before torch would bring in a second libamdhip64 that sees no device
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "librnampnn_hip.so")
+LIB_PATH = os.environ.get("RNAMPNN_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "librnampnn_hip.so")   # RNAMPNN_LIB: A/B builds of the same ABI (tools/build_variant.sh)
 
 PREC_F32, PREC_BF16 = 0, 1
 KMAX = 32
