@@ -129,7 +129,7 @@ def main():
 
     for _ in range(args.warmup):
         logits = model(c, m)
-    model.profile_enable(True)
+    model.profile_enable(True, every=7)     # sampled: 7 is coprime to the 10 fused launches of a forward, so every layer gets timed
     model.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()

@@ -181,8 +181,10 @@ int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float
 
 /* -- measurement ------------------------------------------------------------------------- */
 /* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when
- * enabled, HIP events bracket each of its launches on the caller's stream; _read synchronises
- * the recorded events and returns the summed duration and the launch count since the last reset.
+ * enabled, HIP events bracket its launches on the caller's stream - every `enable`-th launch (1 = all; an event
+ * pair costs ~12 us of stream idle, so a timed production loop samples, e.g. 7 against the 10 launches of a forward);
+ * _read synchronises the recorded events and returns the summed duration and the number of TIMED launches since the
+ * last reset.
  * No reference counterpart (the reference has no profiling hooks). */
 int rnampnn_profile_enable(rnampnn_handle h, int32_t enable);
 int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset);

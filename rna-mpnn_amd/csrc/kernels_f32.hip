@@ -55,6 +55,17 @@ __global__ void k_lengths_from_cu(const int32_t* __restrict__ cu_in, int B, int*
     if (b < B) len[b] = cu_in[b + 1] - cu_in[b];
     if (b <= B) cu[b] = cu_in[b] - cu_in[0];
 }
+// zero up to 8 small regions (the all-zero gather rows of the node tables) in one launch
+__global__ void k_zero_regions(ZeroRegions z) {
+    const int g = blockIdx.x;
+    if (g >= z.n) return;
+    unsigned* p = reinterpret_cast<unsigned*>(z.ptr[g]);
+    for (unsigned i = threadIdx.x; i < z.words[g]; i += blockDim.x) p[i] = 0u;
+}
+void launch_zero_regions(const ZeroRegions& z, hipStream_t s) {
+    if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(z.n), dim3(256), 0, s, z);
+}
+
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s) {
     hipLaunchKernelGGL(k_lengths_from_cu, dim3((pk.B + 256) / 256), dim3(256), 0, s, cu_seqlens, pk.B, pk.len, pk.cu);
 }

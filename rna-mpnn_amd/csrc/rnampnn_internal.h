@@ -27,6 +27,8 @@ struct PackInfo {            // device arrays describing the packed batch
 };
 
 // ---- kernels_f32.hip -------------------------------------------------------------------
+struct ZeroRegions { void* ptr[8]; unsigned words[8]; int n; };       // 4-byte aligned regions, sizes in 32-bit words
+void launch_zero_regions(const ZeroRegions& z, hipStream_t s);
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s);
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s);
 void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, hipStream_t s);

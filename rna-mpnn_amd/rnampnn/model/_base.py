@@ -137,10 +137,10 @@ class NativeModule(nn.Module):
         return C.c_void_p(aligned), C.c_size_t(ws.numel() - (aligned - base))
 
     # ------------------------------------------------------------------ measurement hooks
-    def profile_enable(self, enable: bool = True) -> None:
-        """HIP-event timing of every launch of the dominant (fused ResMPNN edge) kernel."""
+    def profile_enable(self, enable: bool = True, every: int = 1) -> None:
+        """HIP-event timing of every ``every``-th launch of the dominant (fused ResMPNN edge) kernel."""
         self._ensure()
-        _native.check(_native.lib().rnampnn_profile_enable(self._handle.ptr, 1 if enable else 0))
+        _native.check(_native.lib().rnampnn_profile_enable(self._handle.ptr, max(1, int(every)) if enable else 0))
 
     def profile_read(self, reset: bool = True):
         """-> (summed kernel milliseconds, launches) since the last reset (synchronises the events)."""
