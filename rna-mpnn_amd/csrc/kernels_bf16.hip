@@ -239,7 +239,8 @@ __global__ void k_build_embed_image(const float* __restrict__ w0, const float* _
         int e = id - n0;
         int j = e & 7, lane = (e >> 3) & 63, f = e >> 9;
         int ob = f >> 3, ks = f & 7, mb = ks >> 1, sp = ks & 1, r = lane & 31, h = lane >> 5;
-        img[id] = f2bf(w1[(size_t)ch_efrag(ob, r) * RN_D + 32 * mb + 16 * h + 8 * sp + j]);
+        // second Linear: f16 operand (its input, the hidden activation, is produced in f16)
+        img[id] = __builtin_bit_cast(bf16_t, (_Float16)w1[(size_t)ch_efrag(ob, r) * RN_D + 32 * mb + 16 * h + 8 * sp + j]);
     }
     if (id < 128) {
         int ob = id >> 5, m = id & 31, h = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
@@ -873,7 +874,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
             f32x16 acc = init_vec16(b0 + 32 * mb + 16 * h);
 #pragma unroll
             for (int s = 0; s < EMB_KS; ++s) acc = mfma32(img[(mb * EMB_KS + s) * 64 + lane], xf[s], acc);
-            gelu_pack(acc, hb[2 * mb], hb[2 * mb + 1]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {           // packed-f16 GELU, hidden activations stay f16 (as in the fused kernel)
+                const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+                const f16x4 g = x * phi4(x);
+                hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
+                hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         u32x4* ewp = efrag_ptr(e, blk, lane);
@@ -881,13 +888,16 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         for (int ob = 0; ob < 4; ++ob) {
             f32x16 acc = init_vec16(b1p + 32 * ob + 16 * h);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mfma32(img[(4 * EMB_KS + ob * 8 + ks) * 64 + lane], hb[ks], acc);
+            for (int ks = 0; ks < 8; ++ks) acc = mfma32h(img[(4 * EMB_KS + ob * 8 + ks) * 64 + lane], hb[ks], acc);
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {        // padding slots of the block and absent edges are stored as zeros
                 u32x4 nw;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    nw[t] = bl.valid ? pack2(gelu_fast(acc[8 * sp + 2 * t]), gelu_fast(acc[8 * sp + 2 * t + 1])) : 0u;
+                for (int t = 0; t < 4; t += 2) {
+                    const f16x4 ph = phi4(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
+                    nw[t] = bl.valid ? pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) : 0u;
+                    nw[t + 1] = bl.valid ? pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) : 0u;
+                }
                 ewp[64 * (2 * ob + sp)] = nw;
             }
             __builtin_amdgcn_sched_barrier(0);
