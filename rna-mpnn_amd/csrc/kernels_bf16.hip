@@ -40,6 +40,9 @@ __device__ __forceinline__ float lo_bf(unsigned w) { return __uint_as_float(w <<
 __device__ __forceinline__ float hi_bf(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef RN_EXP_NOMFMA
+    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -150,6 +153,9 @@ __device__ __forceinline__ float fma_mix_hi(float a, f16x2 hp, float c) {
     return d;
 }
 __device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef RN_EXP_NOMFMA
+    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
@@ -473,9 +479,15 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     int j;                                             // packed neighbour row of this lane's edge, -1: no edge
     // ---- block state: everything a block needs from HBM (addresses clamped, loads unconditional)
     auto load_index = [&](int b) { const int jr = nbr[RN_IDX(b)]; return (slot_ok && b * npb + q0 < ntot) ? jr : -1; };
-    auto load_e = [&](int b, int s) { ef[s] = efrag_ptr(e, b, lane)[64 * s]; };
+    auto load_e = [&](int b, int s) {
+#ifndef RN_EXP_NOE
+        ef[s] = efrag_ptr(e, b, lane)[64 * s];
+#endif
+    };
     auto gather_q = [&](u32x4 (&dst)[8], const bf16_t* table, int row, int s) {
+#ifndef RN_EXP_NOQ
         dst[s] = (reinterpret_cast<const u32x4*>(table + (size_t)row * RN_D) + h)[2 * s];
+#endif
     };
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     u32x2 pn_e = {0u, 0u}, pn_m = {0u, 0u};
@@ -531,7 +543,9 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             if constexpr (kind == 0 || kind == 2) T = mfma32(wf[s], ef[s], T);
             else if constexpr (kind == 1) T = mfma32h(wf[s], hb[s], T);
             else T = mfma32h(hb[s], wf[s], T);
+#ifndef RN_EXP_NOLDS
             wf[s] = RN_FRAG(RN_NEXT(c), s);            // the register is free again: request the next chain's fragment
+#endif
             if constexpr (i == 4) {
                 constexpr int cn = RN_NEXT(c), kn = cn >> 2;
                 if constexpr (kn == 1) bwn = lds_bwe[(cn & 3) * 64 + lane];
@@ -554,6 +568,15 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         constexpr int kind = c >> 2, cb = c & 3;
         constexpr int gpq = (kind & 1) ? 3 : 2;        // granules per quarter
         constexpr int v = g / gpq, ph = g % gpq;
+#ifdef RN_EXP_NOGELU
+        if constexpr (ph == 0) { gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]); gq = gx; }
+        else if constexpr (ph == 1) {
+            if constexpr (kind == 0 || kind == 2) {
+                hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gx));
+                hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gx));
+            }
+        } else
+#endif
         if constexpr (ph == 0) {
             gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
             gs = __builtin_elementwise_min(gx * gx, h4(9.5f));
@@ -573,7 +596,9 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
             ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
+#ifndef RN_EXP_NOE
             if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
+#endif
         } else if constexpr (!SMALLK && !MSGOUT) {     // mean over the real edges of the residue
             // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly and are taken out again
             if constexpr (v == 0) { s0 = 0.f; s1 = 0.f; gbv = lds_gb[32 * cb + r]; }
