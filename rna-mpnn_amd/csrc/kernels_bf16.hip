@@ -461,9 +461,6 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         blk_end = nblocks; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
     }
     if (blk >= blk_end) return;
-#ifdef RN_STAGGER      // experiment: spread the waves of a CU over the block period so their HBM request bursts do not coincide
-    for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(RN_STAGGER);
-#endif
 
     // chain sequence of a block: c = 0..3 edge Linear 1, 4..7 edge Linear 2, 8..11 message Linear 1, 12..15 message Linear 2
     constexpr int C_FIRST = DO_EDGE ? 0 : 8, C_LAST = DO_MSG ? 15 : 7;
@@ -480,7 +477,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     // ---- block state: everything a block needs from HBM (addresses clamped, loads unconditional)
     auto load_index = [&](int b) { const int jr = nbr[RN_IDX(b)]; return (slot_ok && b * npb + q0 < ntot) ? jr : -1; };
     auto load_e = [&](int b, int s) {
-#ifndef RN_EXP_NOE
+#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOELOAD)
         ef[s] = efrag_ptr(e, b, lane)[64 * s];
 #endif
     };
@@ -596,7 +593,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
             ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
-#ifndef RN_EXP_NOE
+#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
             if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
 #endif
         } else if constexpr (!SMALLK && !MSGOUT) {     // mean over the real edges of the residue
@@ -705,10 +702,12 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             ginv = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
         }
         int jn = -1;
-        // requests for the next block ride behind the MFMAs of the last four chains of this one
+        // requests for the next block: its e fragment s as soon as the last reader of ef[s] - k-step s of the last message
+        // chain of Linear 1 - has issued (4+ chains before it is needed) ...
+#define RN_EXTRA_E(i) do { if constexpr ((i) >= 1 && (i) <= 8) load_e(nb_c, (i) - 1); } while (0)
+        // ... its Q rows and P words behind the MFMAs of the last four chains
 #define RN_EXTRA_N(cc, i) do { if constexpr ((cc) == 0 && (i) == 0) { jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1; stage_p(); } \
-                               if constexpr ((i) == 1 || (i) == 2) load_e(nb_c, 2 * (cc) + (i) - 1);               \
-                               if constexpr ((i) == 3 || (i) == 4) gather_q(q, DO_EDGE ? tab.q_e : tab.q_m, RN_QROW(jn), 2 * (cc) + (i) - 3); } while (0)
+                               if constexpr ((i) == 1 || (i) == 2) gather_q(q, DO_EDGE ? tab.q_e : tab.q_m, RN_QROW(jn), 2 * (cc) + (i) - 1); } while (0)
 #define RN_EXTRA_N0(i) RN_EXTRA_N(0, i)
 #define RN_EXTRA_N1(i) RN_EXTRA_N(1, i)
 #define RN_EXTRA_N2(i) RN_EXTRA_N(2, i)
@@ -723,7 +722,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         }
         if constexpr (DO_EDGE && DO_MSG) RN_SLOT(8, 7, true, RN_NOEXTRA);
         if constexpr (DO_MSG) {
-            RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_NOEXTRA);
+            RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_EXTRA_E);
             STAMP(t3);
             RN_SLOT(12, 11, true, RN_EXTRA_N0); RN_SLOT(13, 12, true, RN_EXTRA_N1);
             STAMP(t4);
@@ -762,6 +761,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #undef RN_EXTRA_N2
 #undef RN_EXTRA_N1
 #undef RN_EXTRA_N0
+#undef RN_EXTRA_E
 #undef RN_EXTRA_N
 #undef RN_NOEXTRA
 #undef RN_SLOT
