@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         }
         if constexpr (DO_EDGE && DO_MSG) RN_SLOT(8, 7, true, RN_NOEXTRA);
         if constexpr (DO_MSG) {
-            RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_EXTRA_E);
+                        RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_EXTRA_E);
             STAMP(t3);
             RN_SLOT(12, 11, true, RN_EXTRA_N0); RN_SLOT(13, 12, true, RN_EXTRA_N1);
             STAMP(t4);
@@ -1274,21 +1274,32 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     const int row_blk = blockIdx.x * 128;
     if (row_blk >= ntot) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    for (int i = tid; i < 4096; i += 256) img[i] = reinterpret_cast<const u32x4*>(j0.img)[i];
-    if (NJOBS > 1) for (int i = tid; i < 4096; i += 256) img[4096 + i] = reinterpret_cast<const u32x4*>(j1.img)[i];
     const int row = row_blk + 32 * wave + r;
     const bool ok = row < ntot;
     const int rr = ok ? row : 0;
     const float* cf = coef + (size_t)pk.node_b[rr] * 256;
+    // the HBM loads of the rows go out first; the weight images (L2-resident) are staged into LDS while they fly
+    f32x4 vx[8][2], va[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c0 = 16 * s + 8 * h;
+        vx[s][0] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0);
+        vx[s][1] = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0 + 4);
+        if (add) {
+            va[s][0] = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0);
+            va[s][1] = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0 + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = tid; i < 4096; i += 256) img[i] = reinterpret_cast<const u32x4*>(j0.img)[i];
+    if (NJOBS > 1) for (int i = tid; i < 4096; i += 256) img[4096 + i] = reinterpret_cast<const u32x4*>(j1.img)[i];
+    __builtin_amdgcn_sched_barrier(0);
     u32x4 xf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int c0 = 16 * s + 8 * h;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0), v1 = *reinterpret_cast<const f32x4*>(x + (size_t)rr * RN_D + c0 + 4);
-        if (add) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0), a1 = *reinterpret_cast<const f32x4*>(add + (size_t)rr * RN_D + c0 + 4);
-            v0 += a0; v1 += a1;
-        }
+        f32x4 v0 = vx[s][0], v1 = vx[s][1];
+        if (add) { v0 += va[s][0]; v1 += va[s][1]; }
         if (coef) {
             f32x4 ca0 = *reinterpret_cast<const f32x4*>(cf + c0), ca1 = *reinterpret_cast<const f32x4*>(cf + c0 + 4);
             f32x4 cb0 = *reinterpret_cast<const f32x4*>(cf + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4);
