@@ -135,6 +135,22 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<N, I + 1>(f);
     }
 }
+// Copy a 64 KiB fragment image (4096 x 16 B) into LDS with NT threads: all of a thread's loads are issued before its
+// first LDS write (a plain copy loop compiles to load -> wait -> write per iteration, i.e. one L2 round trip each).
+template <int NT>
+__device__ __forceinline__ void stage_image(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
+    constexpr int PER = 4096 / NT;
+    static_assert(4096 % NT == 0, "image size must be a multiple of the thread count");
+    constexpr int BATCH = PER < 8 ? PER : 8;
+#pragma unroll
+    for (int b0 = 0; b0 < PER; b0 += BATCH) {
+        u32x4 t[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) t[i] = src[tid + (b0 + i) * NT];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) dst[tid + (b0 + i) * NT] = t[i];
+    }
+}
 // x as a (hi, lo) pair of bf16 in one word (hi in the low half): x = hi + lo to ~16 bits.  Operand of the k = 2 MFMAs that
 // add a per-row constant (bias, P row) to an accumulator tile.
 __device__ __forceinline__ unsigned split_word(float x) {
@@ -406,8 +422,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
     float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
     u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_gb + 128);                   // [2][lane]: constant 0/1 routing fragments
-    if (DO_EDGE) for (int i = tid; i < 4096; i += NW * 64) img_e[i] = reinterpret_cast<const u32x4*>(we.img)[i];
-    if (DO_MSG) for (int i = tid; i < 4096; i += NW * 64) img_m[i] = reinterpret_cast<const u32x4*>(wm.img)[i];
+    if (DO_EDGE) stage_image<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
+    if (DO_MSG) stage_image<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
     if (tid < 128) {
         // The gathered Q row (bf16, fetched in the e-fragment layout: q[s] = channels 16s+8h..) is added by the MATRIX
         // pipe: two extra MFMAs per channel block whose A operand is the constant 0/1 matrix that routes channel
@@ -841,7 +857,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
     u32x4* img = reinterpret_cast<u32x4*>(smem);
     const int NFRAG = 4 * EMB_KS + 32;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NFRAG * 64; i += 512) img[i] = reinterpret_cast<const u32x4*>(img_g)[i];
+    {   // 60 KiB image: loads of a thread first, LDS writes after (see stage_image)
+        u32x4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (tid + i * 512 < NFRAG * 64) t[i] = reinterpret_cast<const u32x4*>(img_g)[tid + i * 512];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (tid + i * 512 < NFRAG * 64) img[tid + i * 512] = t[i];
+    }
     __syncthreads();
     const int ntot = pk.cu[pk.B];
     const int npb = k > 16 ? 1 : 32 / k;
@@ -1291,8 +1313,8 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    for (int i = tid; i < 4096; i += 256) img[i] = reinterpret_cast<const u32x4*>(j0.img)[i];
-    if (NJOBS > 1) for (int i = tid; i < 4096; i += 256) img[4096 + i] = reinterpret_cast<const u32x4*>(j1.img)[i];
+    stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
+    if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
     __builtin_amdgcn_sched_barrier(0);
     u32x4 xf[8];
 #pragma unroll
