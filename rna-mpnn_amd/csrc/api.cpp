@@ -57,7 +57,6 @@ struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     int w[2], b[2];           // RawT indices
     size_t pq_t, pq_b;        // derived f32: [128][256] K-major (P | Q parts of Linear 0), bias [b1 | 0]
     size_t wc_t, w2_t;        // derived f32: e-part of Linear 0 and Linear 1, K-major
-    size_t pq_wb;             // derived bf16 [256][128]  (fast path node GEMM, stage API)
     size_t pq_img;            // derived bf16 [P | Q] fragment image for the fused node-update kernel
     size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
     size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
@@ -181,7 +180,6 @@ static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     m.pq_b = add_der(c, 256 * sizeof(float));
     m.wc_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
     m.w2_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
-    m.pq_wb = add_der(c, (size_t)256 * RN_D * sizeof(bf16_t));
     m.pq_img = add_der(c, (size_t)64 * 1024);
     m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
     m.b2p = add_der(c, RN_D * sizeof(float));
@@ -354,8 +352,6 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
     if (m.depth > 1) launch_transpose(rawp(c, m.w[1]), RN_D, RN_D, RN_D, derp<float>(c, m.w2_t), RN_D, s);
     if (c->cfg.precision == RNAMPNN_PREC_BF16) {
         // node GEMM weights [P rows | Q rows] = W0[:, 0:128] and W0[:, 128:256], bf16 [256][128]
-        launch_convert_rows_bf16(w0, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb), s);
-        launch_convert_rows_bf16(w0 + RN_D, 3 * RN_D, RN_D, RN_D, RN_D, derp<bf16_t>(c, m.pq_wb) + RN_D * RN_D, s);
         launch_build_pq_image(w0, derp<bf16_t>(c, m.pq_img), s);
         launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
                                derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
@@ -532,9 +528,9 @@ static void run_ffn(Run& r, const Chain& ch, const std::vector<Lin>& ffn, const 
 
 static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq, bf16_t* q) {
     rnampnn_ctx* c = r.c;
-    if (r.fast)     // P -> f32 [N][128] (in pq), Q -> bf16 [N][128] (in q)
-        launch_gemm_bf16(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<bf16_t>(c, m.pq_wb),
-                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, RN_D, q, RN_D, RN_D, r.s);
+    if (r.fast)     // the fused node kernel without residual / norm: P -> split-bf16 words (in pq), Q -> bf16 (in q)
+        launch_node_update(r.pk, h, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, derp<bf16_t>(c, m.pq_img),
+                           derp<float>(c, m.pq_b), pq, q, nullptr, nullptr, nullptr, nullptr, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<float>(c, m.pq_t),
                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);

@@ -163,6 +163,10 @@ def test_standalone_stage_modules_match_oracle():
     assert (h1.cpu() - o_h1).abs().max() < 2e-4
     assert ((e1.cpu() - o_e1) * valid).abs().max() < 2e-4
     assert torch.equal(e.cpu(), o_e) or (e.cpu() - o_e).abs().max() < 2e-4     # caller's e is not mutated
+    fast, _ = load(ResMPNN(128, 128, 2, 2, 0.4, precision="bf16"))                # same layer through the bf16 MFMA kernels
+    hb, eb = fast(h, e, idx, mt)
+    assert (hb.cpu() - o_h1).abs().max() < 3e-2 and ((eb.cpu() - o_e1) * valid).abs().max() < 5e-2
+    assert (fast.message(h, e, idx, mt).cpu() - o_msg).abs().max() < 3e-2
 
     bert, sdb = load(RNABert(padding_len=100, res_embedding_dim=128, num_attn_layers=2, num_heads=8, ffn_dim=256,
                              num_ffn_layers=2, precision="f32"))
