@@ -470,7 +470,7 @@ static void gemm(Run& r, const Lin& l, const float* X, int ldx, float* Y, int ld
     int k2 = K1 < 0 ? 0 : l.in_pad - K1;
     if (r.fast && l.out >= 64)
         launch_gemm_bf16(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<bf16_t>(c, l.wb), rawp(c, l.b), l.out,
-                         l.gelu ? 1 : 0, res, ldres, Y, ldy, nullptr, 0, 0, r.s);
+                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, X, ldx, k1, X2, ldx2, k2, derp<float>(c, l.wt), rawp(c, l.b), l.out,
                         l.gelu ? 1 : 0, res, ldres, Y, ldy, r.s);

@@ -21,7 +21,7 @@ static inline size_t efrag_bytes(int nmax, int k) { int npb = k > 16 ? 1 : 32 / 
 // node-level Linear on MFMA: Y = act([X | X2] . W^T + bias) (+ res);  W bf16 [N][K] row-major
 void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
                       const bf16_t* W, const float* bias, int N, int act, const float* res, int ldres,
-                      float* Y, int ldy, bf16_t* Yb, int ldyb, int col_split, hipStream_t s);   // cols >= col_split -> bf16 Yb (if Yb)
+                      float* Y, int ldy, hipStream_t s);   // cols >= col_split -> bf16 Yb (if Yb)
 void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const int* nbr, const bf16_t* img,
                             const float* b0, const float* b1p, bf16_t* e, hipStream_t s);
 // node tables: p_* f32 [N+1][128] (h.Wa^T + b1), q_* bf16 [N+1][128] (h.Wb^T; row Nmax = zeros)

@@ -972,8 +972,7 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
 #define GB_LD 72
 __global__ void __launch_bounds__(256) k_gemm_bf16(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx, int K1,
         const float* __restrict__ X2, int ldx2, int K2, const bf16_t* __restrict__ W, const float* __restrict__ bias,
-        int N, int act, const float* __restrict__ res, int ldres, float* __restrict__ Y, int ldy,
-        bf16_t* __restrict__ Yb, int ldyb, int col_split) {
+        int N, int act, const float* __restrict__ res, int ldres, float* __restrict__ Y, int ldy) {
     __shared__ __attribute__((aligned(16))) bf16_t As[128 * GB_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * GB_LD];
     const int ntot = *ntot_p;
@@ -1043,33 +1042,50 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(const int* __restrict__ ntot_
                 for (int b = 0; b < 2; ++b) acc[a][b] = mfma32(af[a], bfm[b], acc[a][b]);
         }
     }
+    // epilogue: the 16 rows a lane holds of one 32x32 tile are handled together - the residual loads go out as a batch
+    // (a per-element load -> wait -> store chain costs one L2 round trip per element) and the activation is a uniform branch
+    const bool has_res = res != nullptr;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = col0 + 64 * wc + 32 * b + r;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        const bool colok = col < N;
+        const int cc = colok ? col : 0;
+        const float bv = bias ? bias[cc] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+            const int rbase = row0 + 64 * wr + 32 * a + 4 * h;
+            float v[16], rv[16];
+            if (has_res) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = row0 + 64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (row < ntot) {
-                    float v = acc[a][b][i] + bv;
-                    if (act == 1) v = gelu_erf(v);
-                    if (res) v += res[(size_t)row * ldres + col];
-                    if (Yb && col >= col_split) Yb[(size_t)row * ldyb + (col - col_split)] = f2bf(v);
-                    else Y[(size_t)row * ldy + col] = v;
+                for (int i = 0; i < 16; ++i) {
+                    const int row = rbase + (i & 3) + 8 * (i >> 2);
+                    rv[i] = res[(size_t)(row < ntot ? row : ntot - 1) * ldres + cc];
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i] + bv;
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = gelu_erf(v[i]);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += rv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = rbase + (i & 3) + 8 * (i >> 2);
+                if (colok && row < ntot) Y[(size_t)row * ldy + col] = v[i];
+            }
+        }
     }
 }
 
 void launch_gemm_bf16(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
                       const bf16_t* W, const float* bias, int N, int act, const float* res, int ldres,
-                      float* Y, int ldy, bf16_t* Yb, int ldyb, int col_split, hipStream_t s) {
+                      float* Y, int ldy, hipStream_t s) {
     dim3 grid((mmax + 127) / 128, (N + 127) / 128);
-    hipLaunchKernelGGL(k_gemm_bf16, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, W, bias, N, act, res, ldres, Y, ldy,
-                       Yb, ldyb, col_split);
+    hipLaunchKernelGGL(k_gemm_bf16, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, W, bias, N, act, res, ldres, Y, ldy);
 }
 
 // ------------------------------------------------------------------------------------------
