@@ -1332,22 +1332,37 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
     if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
     __builtin_amdgcn_sched_barrier(0);
+    // the biases of the P halves go through LDS too (a global read per channel block would expose an L2 round trip each)
+    float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);
+    if (tid < 128) lds_bias[tid] = j0.bias[tid];
+    else if (NJOBS > 1) lds_bias[tid] = j1.bias[tid - 128];
+    // residual, then GraphNorm as one branch-free pass (its 32 coefficient loads go out together), then stores + bf16 pack
+    if (add) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { vx[s][0] += va[s][0]; vx[s][1] += va[s][1]; }
+    }
+    if (coef) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            const f32x4 ca0 = *reinterpret_cast<const f32x4*>(cf + c0), ca1 = *reinterpret_cast<const f32x4*>(cf + c0 + 4);
+            const f32x4 cb0 = *reinterpret_cast<const f32x4*>(cf + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4);
+            vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
+        }
+    }
     u32x4 xf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int c0 = 16 * s + 8 * h;
-        f32x4 v0 = vx[s][0], v1 = vx[s][1];
-        if (add) { v0 += va[s][0]; v1 += va[s][1]; }
-        if (coef) {
-            f32x4 ca0 = *reinterpret_cast<const f32x4*>(cf + c0), ca1 = *reinterpret_cast<const f32x4*>(cf + c0 + 4);
-            f32x4 cb0 = *reinterpret_cast<const f32x4*>(cf + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4);
-            v0 = v0 * ca0 + cb0; v1 = v1 * ca1 + cb1;
-        }
-        if (ok && h_out) {
-            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0) = v0;
-            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = v1;
-        }
+        const f32x4 v0 = vx[s][0], v1 = vx[s][1];
         xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+    }
+    if (ok && h_out) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0) = vx[s][0];
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = vx[s][1];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -1357,7 +1372,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
 #pragma unroll
         for (int ob = 0; ob < 8; ++ob) {
             f32x16 acc;
-            if (ob < 4) acc = init_vec16(jbq.bias + 32 * ob + 16 * h);
+            if (ob < 4) acc = init_vec16(lds_bias + jb * 128 + 32 * ob + 16 * h);
             else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1404,13 +1419,13 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     dim3 grid((pk.Nmax + 127) / 128);
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute((const void*)k_node_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)k_node_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)k_node_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)k_node_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024);
         done = true;
     }
     const float* cf = scale ? coef : nullptr;
-    if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536, s, pk, x, add, cf, h_out, j0, j1);
-    else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072, s, pk, x, add, cf, h_out, j0, j1);
+    if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536 + 1024, s, pk, x, add, cf, h_out, j0, j1);
+    else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072 + 1024, s, pk, x, add, cf, h_out, j0, j1);
 }
 
 // ------------------------------------------------------------------------------------------
