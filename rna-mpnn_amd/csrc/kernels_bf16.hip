@@ -1171,19 +1171,34 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
     constexpr int HK = H / 16, HB = H / 32, OB = NOUT / 32;
     constexpr int NCH0 = HB * (K0 / 16) / 32, NCHH = HB * HK / 32, NCHL = OB * HK / 32, NCH_T = NCH0 + NH * NCHH + NCHL;
     // biases -> LDS (layer l at l*H), input rows -> B fragments (natural k order; X for k < 128, X2 beyond)
+    // (all loads of a phase are issued before their first use: a load -> wait -> use chain per iteration costs a memory
+    //  round trip each; rows beyond the batch read row ntot - 1 and are never stored)
+    {
+        constexpr int NBL = ((NH + 1) * H + NOUT + 255) / 256;
+        float bv[NBL];
 #pragma unroll
-    for (int l = 0; l < NH + 2; ++l) {
-        const int nb = l == NH + 1 ? NOUT : H;
-        for (int i = tid; i < nb; i += 256) bias_lds[l * H + i] = w.bias[l][i];
+        for (int t = 0; t < NBL; ++t) {
+            const int idx = tid + 256 * t;                     // position in the concatenated [layer][channel] list
+            const int l = idx / H < NH + 1 ? idx / H : NH + 1, i = idx - l * H;
+            bv[t] = (idx < (NH + 1) * H + NOUT) ? w.bias[l][i] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NBL; ++t) if (tid + 256 * t < (NH + 1) * H + NOUT) bias_lds[tid + 256 * t] = bv[t];
     }
     u32x4 a[32], b[32];
+    {
+        const int rr = row_ok ? row : ntot - 1;
+        f32x4 v0[K0 / 16], v1[K0 / 16];
 #pragma unroll
-    for (int s = 0; s < K0 / 16; ++s) {
-        const int kk = 16 * s + 8 * h;
-        const float* src = (K0 > 128 && kk >= 128) ? X2 + (size_t)row * ldx2 + (kk - 128) : X + (size_t)row * ldx + kk;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (row_ok) { v0 = *reinterpret_cast<const f32x4*>(src); v1 = *reinterpret_cast<const f32x4*>(src + 4); }
-        a[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+        for (int s = 0; s < K0 / 16; ++s) {
+            const int kk = 16 * s + 8 * h;
+            const float* src = (K0 > 128 && kk >= 128) ? X2 + (size_t)rr * ldx2 + (kk - 128) : X + (size_t)rr * ldx + kk;
+            v0[s] = *reinterpret_cast<const f32x4*>(src);
+            v1[s] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < K0 / 16; ++s)
+            a[s] = u32x4{pack2(v0[s][0], v0[s][1]), pack2(v0[s][2], v0[s][3]), pack2(v1[s][0], v1[s][1]), pack2(v1[s][2], v1[s][3])};
     }
     __syncthreads();                                          // biases visible; no DMA is in flight yet
     const u32x4* img = reinterpret_cast<const u32x4*>(w.img);
