@@ -557,6 +557,7 @@ __global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const fl
         return v;
     };
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int r = g; r < n; r += 8) { float4 v = ld(r); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     red[g][cq] = s;
     __syncthreads();
@@ -570,6 +571,7 @@ __global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const fl
     __syncthreads();
     const float4 mean = stat[cq];
     float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int r = g; r < n; r += 8) {
         float4 v = ld(r);
         float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
@@ -587,6 +589,7 @@ __global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const fl
     sd.z = sqrtf((t.z + pad * mean.z * mean.z) / fn + kSEPS); sd.w = sqrtf((t.w + pad * mean.w * mean.w) / fn + kSEPS);
     const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
     float4* yb = reinterpret_cast<float4*>(y + base) + cq;
+#pragma unroll 4
     for (int r = g; r < n; r += 8) {
         float4 v = ld(r), o;
         o.x = (v.x - mean.x) / sd.x * sc.x + sh.x; o.y = (v.y - mean.y) / sd.y * sc.y + sh.y;
@@ -595,9 +598,85 @@ __global__ void __launch_bounds__(256) k_graph_norm_packed(PackInfo pk, const fl
     }
 }
 
+// Same, for RNAs of at most 8 * NR residues: every thread keeps its <= NR rows in registers, so the rows are read from
+// memory once (all loads in flight together) instead of three times in dependent loops.
+template <int NR>
+__global__ void __launch_bounds__(256) k_graph_norm_packed_reg(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int t_tot) {
+    __shared__ float4 red[8][32];
+    __shared__ float4 stat[32];
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const size_t base = (size_t)pk.cu[b] * RN_D;
+    const int cq = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
+    const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
+    float4 v[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = g + 8 * i, rc = r < n ? r : n - 1;
+        v[i] = xb[(size_t)rc * 32];
+    }
+    if (ab) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = g + 8 * i, rc = r < n ? r : n - 1;
+            const float4 a = ab[(size_t)rc * 32];
+            v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+        }
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        if (g + 8 * i < n) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    red[g][cq] = s;
+    __syncthreads();
+    if (g == 0) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { float4 u = red[i][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float inv = 1.0f / (float)n;
+        stat[cq] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    __syncthreads();
+    const float4 mean = stat[cq];
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        if (g + 8 * i < n) {
+            const float dx = v[i].x - mean.x, dy = v[i].y - mean.y, dz = v[i].z - mean.z, dw = v[i].w - mean.w;
+            ss.x = fmaf(dx, dx, ss.x); ss.y = fmaf(dy, dy, ss.y); ss.z = fmaf(dz, dz, ss.z); ss.w = fmaf(dw, dw, ss.w);
+        }
+    __syncthreads();
+    red[g][cq] = ss;
+    __syncthreads();
+    float4 t = red[0][cq];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { float4 u = red[i][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    const float pad = (float)(t_tot - n), fn = (float)n;
+    float4 sd;
+    sd.x = sqrtf((t.x + pad * mean.x * mean.x) / fn + kSEPS); sd.y = sqrtf((t.y + pad * mean.y * mean.y) / fn + kSEPS);
+    sd.z = sqrtf((t.z + pad * mean.z * mean.z) / fn + kSEPS); sd.w = sqrtf((t.w + pad * mean.w * mean.w) / fn + kSEPS);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+    float4* yb = reinterpret_cast<float4*>(y + base) + cq;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = g + 8 * i;
+        if (r < n) {
+            float4 o;
+            o.x = (v[i].x - mean.x) / sd.x * sc.x + sh.x; o.y = (v[i].y - mean.y) / sd.y * sc.y + sh.y;
+            o.z = (v[i].z - mean.z) / sd.z * sc.z + sh.z; o.w = (v[i].w - mean.w) / sd.w * sc.w + sh.w;
+            yb[(size_t)r * 32] = o;
+        }
+    }
+}
+
 void launch_graph_norm_packed(const PackInfo& pk, const float* x, const float* add, float* y, const float* scale,
                               const float* shift, int t_tot, hipStream_t s) {
-    hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
+    // (same arithmetic, same summation order per thread: the register variant is bit-identical to the loop variant)
+    if (pk.T <= 160) hipLaunchKernelGGL(k_graph_norm_packed_reg<20>, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
+    else hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
 }
 
 // Stand-alone GraphNormalization on the reference's padded layout, any D, mask by value.
