@@ -1276,11 +1276,28 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
     const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
     const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-    for (int r = g; r < n; r += 32) {
-        float4 v = xb[(size_t)r * 32];
-        if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    auto accum = [&](float4 v) {
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+    };
+    if (n <= 160) {         // all loads of the thread in flight together (rows clamped, contributions predicated)
+        float4 v[5], a[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const int r = g + 32 * i, rc = r < n ? r : n - 1; v[i] = xb[(size_t)rc * 32]; }
+        if (ab) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { const int r = g + 32 * i, rc = r < n ? r : n - 1; a[i] = ab[(size_t)rc * 32]; }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (g + 32 * i < n) accum(v[i]);
+    } else {
+        for (int r = g; r < n; r += 32) {
+            float4 v = xb[(size_t)r * 32];
+            if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            accum(v);
+        }
     }
     // reduce the 32 row groups: 4 lanes-of-8 per wave via shuffles, then 4 waves via LDS
 #pragma unroll
