@@ -458,3 +458,23 @@ def test_full_size_properties_c2():
         assert torch.equal(part, a[it][:, :ts]), rank
     ref, _ = _oracle(hp, sd, coords[:6], mask[:6])            # T of the slice = global T: same normalisation
     assert (a[:6].cpu() - ref).abs().max() < BF16_LOGIT_TOL
+
+
+@pytest.mark.parametrize("k", [4, 5, 7, 9, 16, 17, 25, 31])
+def test_bf16_fast_path_tracks_f32_path_across_neighbourhood_sizes(k):
+    """The fused bf16 kernel has two block shapes (k > 16: one residue per 32-edge block; k <= 16: 32 / k residues per
+    block with the multi-residue P injection) and padding slots when k does not divide 32: every shape must stay
+    within the bf16 tolerance of the exact-f32 kernels on a ragged batch with very short RNAs (phantom neighbours,
+    absent edges, rows with no edge at all)."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    lens = [1, 2, 3, k, k + 1, 2 * k + 3, 37, 64, 5, 90]
+    coords, mask, _ = synth.synth_batch(lens, first_index=300 + k)
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=k, padding_len=int(mask.shape[1]), num_res_mpnn_layers=3)
+    exact, _ = _model(hp, state_dict_shapes(hp), "f32")
+    fast, _ = _model(hp, state_dict_shapes(hp), "bf16")
+    c, m = torch.from_numpy(coords), torch.from_numpy(mask)
+    a, b = exact(c, m).cpu(), fast(c, m).cpu()
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max() < BF16_LOGIT_TOL, float((a - b).abs().max())
+    assert (b * (1 - m).unsqueeze(-1) == 0).all()
