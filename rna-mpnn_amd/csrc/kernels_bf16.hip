@@ -1116,6 +1116,14 @@ __device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
                                          (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
 }
+// one of the 8 DMA pieces of chunk c (issued between the MFMAs of the chunk that runs three chunks earlier: the ~100
+// cycles a DMA holds the wave's issue then pass under a busy matrix pipe instead of in front of it)
+__device__ __forceinline__ void chain_issue_piece(const u32x4* __restrict__ img, u32x4* ring, int c, int tid, int i) {
+    const u32x4* src = img + (size_t)c * 2048 + tid + i * 256;
+    u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63) + i * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
 __device__ __forceinline__ void chain_wait(int chunks_after) {       // folded to one s_waitcnt after unrolling
     if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1134,14 +1142,22 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = C0 + ch;
         chain_wait(NCH_T - 1 - c < 2 ? NCH_T - 1 - c : 2);
-        if (c + 3 < NCH_T) chain_issue(img, ring, c + 3, tid);
-        const u32x4* buf = ring + (c % CH_RING) * 2048;
+        const u32x4* buf = ring + (c % CH_RING) * 2048 + lane;
+        // the 32 weight fragments of the chunk go through an 8-deep register ring, so that no MFMA waits on its LDS read
+        u32x4 fr[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) fr[m] = buf[m * 64];
 #pragma unroll
         for (int o = 0; o < OPC; ++o) {
             const int ob = ch * OPC + o;
             f32x16 acc = init_vec16(bias_lds + 32 * ob + 16 * h);
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) acc = mfma32(buf[(o * NKS + ks) * 64 + lane], in[ks], acc);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int m = o * NKS + ks;                    // MFMA number within the chunk (32 per chunk)
+                acc = mfma32(fr[m & 7], in[ks], acc);
+                if (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
+                if (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
+            }
             if (!LAST) {
                 gelu_pack(acc, out[2 * ob], out[2 * ob + 1]);
             } else if (row_ok) {
