@@ -1154,12 +1154,18 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const int m = o * NKS + ks;                    // MFMA number within the chunk (32 per chunk)
-                acc = mfma32(fr[m & 7], in[ks], acc);
+                acc = C0 == 0 ? mfma32(fr[m & 7], in[ks], acc) : mfma32h(fr[m & 7], in[ks], acc);    // hidden activations are f16
                 if (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
                 if (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
             }
             if (!LAST) {
-                gelu_pack(acc, out[2 * ob], out[2 * ob + 1]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {       // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
+                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+                    const f16x4 g = x * phi4(x);
+                    out[2 * ob][t] = __builtin_bit_cast(unsigned, lo2(g));
+                    out[2 * ob + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+                }
             } else if (row_ok) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -1246,7 +1252,8 @@ __global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, 
     int ob = f / nks, ks = f % nks, r = lane & 31, h = lane >> 5;
     int row = ch_nat(ob, r);
     int col = first ? 16 * ks + 8 * h + j : 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j;
-    dst[id] = (row < n_real && col < K_real) ? f2bf(wraw[(size_t)row * K_real + col]) : (bf16_t)0;
+    const float wv = (row < n_real && col < K_real) ? wraw[(size_t)row * K_real + col] : 0.f;
+    dst[id] = first ? f2bf(wv) : __builtin_bit_cast(bf16_t, (_Float16)wv);      // layers after the first consume f16 activations
 }
 void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s) {
     int total = (N / 32) * (K / 16) * 512;
