@@ -857,6 +857,9 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
     u32x4* img = reinterpret_cast<u32x4*>(smem);
     const int NFRAG = 4 * EMB_KS + 32;
     const int tid = threadIdx.x;
+    float* lds_b = reinterpret_cast<float*>(smem + (size_t)NFRAG * 1024);      // both bias vectors: a global read per channel block
+    if (tid < 128) lds_b[tid] = b0[tid];                                        // of every edge block would expose an L2 round trip each
+    else if (tid < 256) lds_b[tid] = b1p[tid - 128];
     {   // 60 KiB image: loads of a thread first, LDS writes after (see stage_image)
         u32x4 t[8];
 #pragma unroll
@@ -918,7 +921,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         u32x4 hb[8];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-            f32x16 acc = init_vec16(b0 + 32 * mb + 16 * h);
+            f32x16 acc = init_vec16(lds_b + 32 * mb + 16 * h);
 #pragma unroll
             for (int s = 0; s < EMB_KS; ++s) acc = mfma32(img[(mb * EMB_KS + s) * 64 + lane], xf[s], acc);
 #pragma unroll
@@ -933,7 +936,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         u32x4* ewp = efrag_ptr(e, blk, lane);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            f32x16 acc = init_vec16(b1p + 32 * ob + 16 * h);
+            f32x16 acc = init_vec16(lds_b + 128 + 32 * ob + 16 * h);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc = mfma32h(img[(4 * EMB_KS + ob * 8 + ks) * 64 + lane], hb[ks], acc);
 #pragma unroll
@@ -959,7 +962,7 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
     int grid = (max_blocks + 7) / 8;
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     if (grid < 1) grid = 1;
-    size_t lds = (size_t)(4 * EMB_KS + 32) * 1024;
+    size_t lds = (size_t)(4 * EMB_KS + 32) * 1024 + 1024;
     hipLaunchKernelGGL(k_edge_embed_bf16, dim3(grid), dim3(512), lds, s, pk, k, geom, nbr, img, b0, b1p, e);
 }
 
