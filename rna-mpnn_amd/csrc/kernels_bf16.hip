@@ -1505,13 +1505,11 @@ __global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const 
     const int tid = threadIdx.x;
     for (int idx = tid; idx < nkb * 64; idx += 512) {          // K rows
         const int key = idx >> 1, hh = idx & 1;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (key < n) {
-            const float* kp = qkv + (size_t)(base + key) * 384 + 128 + hd * 16 + 8 * hh;
-            f32x4 a = *reinterpret_cast<const f32x4*>(kp), c = *reinterpret_cast<const f32x4*>(kp + 4);
-            v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
-        }
-        Kimg[idx] = v;
+        // (rows clamped and the result masked: a conditional load per element would serialise into one memory round trip each)
+        const float* kp = qkv + (size_t)(base + (key < n ? key : n - 1)) * 384 + 128 + hd * 16 + 8 * hh;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(kp), c = *reinterpret_cast<const f32x4*>(kp + 4);
+        const u32x4 v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
+        Kimg[idx] = key < n ? v : u32x4{0u, 0u, 0u, 0u};
     }
     for (int idx = tid; idx < nkb * 64; idx += 512) {          // V^T fragments
         const int d = idx & 15, hh = (idx >> 4) & 1, sblk = (idx >> 5) & 1, kb = idx >> 6;
@@ -1519,7 +1517,12 @@ __global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
-            vals[j] = key < n ? qkv[(size_t)(base + key) * 384 + 256 + hd * 16 + d] : 0.f;
+            vals[j] = qkv[(size_t)(base + (key < n ? key : n - 1)) * 384 + 256 + hd * 16 + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+            if (key >= n) vals[j] = 0.f;
         }
         Vt[idx] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
     }
