@@ -422,6 +422,48 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
     float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
     u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_gb + 128);                   // [2][lane]: constant 0/1 routing fragments
+    const int ntot = pk.cu[pk.B];
+    const int npb = SMALLK ? 32 / k : 1;              // SMALLK <=> k <= 16
+    const int nblocks = (ntot + npb - 1) / npb;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int zero_row = pk.Nmax;
+    const int q0 = SMALLK ? r / k : 0;                // residue of the block this lane's edge slot belongs to
+    const bool slot_ok = SMALLK ? q0 < npb : r < k;
+    const int last_idx = ntot * k - 1;
+    const unsigned ones_w = h == 0 ? 0x3F803F80u : 0u;     // k = 0, 1 of lane half 0
+
+    // XCD-aware block mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  XCD x
+    // owns a CONTIGUOUS eighth of the residues (whole RNAs, mostly), so the Q / P rows its gathers touch (2 MB instead of
+    // the full 16 MB tables) stay resident in that L2 next to the streaming e blocks; within the eighth the waves stride.
+    int blk, blk_end, stride;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (nblocks + 7) >> 3, x = blockIdx.x & 7;
+        blk_end = min(nblocks, (x + 1) * chunk);
+        stride = (gridDim.x >> 3) * NW;
+        blk = x * chunk + (blockIdx.x >> 3) * NW + wave;
+    } else {
+        blk_end = nblocks; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
+    }
+    // The first block's HBM requests (neighbour indices, e fragments, P words) go out BEFORE the weight images are staged
+    // into LDS, so that their latency passes under the staging instead of after it (a wave without a block reads block 0
+    // and discards it; it must stay for the cooperative staging).
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x4 ef[8];
+    u32x2 pn_e = {0u, 0u}, pn_m = {0u, 0u};
+    int jraw_first = -1;
+    if (nblocks > 0) {
+        const int b0 = blk < blk_end ? blk : 0;
+        const int i0 = b0 * npb * k + r;
+        jraw_first = nbr[i0 > last_idx ? last_idx : i0];
+#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOELOAD)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ef[s] = efrag_ptr(e, b0, lane)[64 * s];
+#endif
+        if (!SMALLK) {
+            if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b0 * RN_D + 2 * lane);
+            if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b0 * RN_D + 2 * lane);
+        }
+    }
     if (DO_EDGE) stage_image<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
     if (DO_MSG) stage_image<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
     if (tid < 128) {
@@ -450,32 +492,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     }
     __syncthreads();
 
-    const int ntot = pk.cu[pk.B];
-    const int npb = SMALLK ? 32 / k : 1;              // SMALLK <=> k <= 16
-    const int nblocks = (ntot + npb - 1) / npb;
-    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int zero_row = pk.Nmax;
-    const int q0 = SMALLK ? r / k : 0;                // residue of the block this lane's edge slot belongs to
-    const bool slot_ok = SMALLK ? q0 < npb : r < k;
-    const int last_idx = ntot * k - 1;
-    const unsigned ones_w = h == 0 ? 0x3F803F80u : 0u;     // k = 0, 1 of lane half 0
     const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
     const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
     unsigned bwn = 0u;                                 // bias word of the NEXT chain (second Linears), requested mid-chain
     float gbv = 0.f;                                   // GELU(bias) of the channel whose mean is being formed
-
-    // XCD-aware block mapping: consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  XCD x
-    // owns a CONTIGUOUS eighth of the residues (whole RNAs, mostly), so the Q / P rows its gathers touch (2 MB instead of
-    // the full 16 MB tables) stay resident in that L2 next to the streaming e blocks; within the eighth the waves stride.
-    int blk, blk_end, stride;
-    if ((gridDim.x & 7) == 0) {
-        const int chunk = (nblocks + 7) >> 3, x = blockIdx.x & 7;
-        blk_end = min(nblocks, (x + 1) * chunk);
-        stride = (gridDim.x >> 3) * NW;
-        blk = x * chunk + (blockIdx.x >> 3) * NW + wave;
-    } else {
-        blk_end = nblocks; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
-    }
     if (blk >= blk_end) return;
 
     // chain sequence of a block: c = 0..3 edge Linear 1, 4..7 edge Linear 2, 8..11 message Linear 1, 12..15 message Linear 2
@@ -486,12 +506,11 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #define RN_QROW(jj) ((jj) >= 0 ? ((jj) > zero_row ? zero_row : (jj)) : zero_row)
 #define RN_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-    u32x4 ef[8], q[8], hb[8], wf[8];                  // q: gathered Q rows of the MLP whose first Linear runs next
+    u32x4 q[8], hb[8], wf[8];                         // q: gathered Q rows of the MLP whose first Linear runs next
     f32x16 tA, tB;                                     // accumulator tiles: chain c runs in (c & 1 ? tB : tA)
     u32x4 pwe = {0u, 0u, 0u, 0u}, pwm = {0u, 0u, 0u, 0u};      // !SMALLK: P words of the block's residue, [mb]
     int j;                                             // packed neighbour row of this lane's edge, -1: no edge
     // ---- block state: everything a block needs from HBM (addresses clamped, loads unconditional)
-    auto load_index = [&](int b) { const int jr = nbr[RN_IDX(b)]; return (slot_ok && b * npb + q0 < ntot) ? jr : -1; };
     auto load_e = [&](int b, int s) {
 #if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOELOAD)
         ef[s] = efrag_ptr(e, b, lane)[64 * s];
@@ -502,8 +521,6 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         dst[s] = (reinterpret_cast<const u32x4*>(table + (size_t)row * RN_D) + h)[2 * s];
 #endif
     };
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    u32x2 pn_e = {0u, 0u}, pn_m = {0u, 0u};
     auto load_p = [&](int b) {                         // !SMALLK: the residue's P words (coalesced 512 B rows), requested early ...
         if (SMALLK) return;
         if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + 2 * lane);
@@ -656,15 +673,12 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #define RN_NGRAN(c) ((((c) >> 2) & 1) ? 12 : 8)
 
     // ---- prologue: state of the first block, fragments of its first chain
-    j = load_index(blk);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) load_e(blk, s);
+    j = (slot_ok && blk * npb + q0 < ntot) ? jraw_first : -1;
     {
         const int qr = RN_QROW(j);
 #pragma unroll
         for (int s = 0; s < 8; ++s) gather_q(q, DO_EDGE ? tab.q_e : tab.q_m, qr, s);
     }
-    load_p(blk);
     stage_p();
     fetch_p();
 #pragma unroll
