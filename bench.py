@@ -189,7 +189,7 @@ def main():
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_traffic.json",
-                         "limiter": "no single unit: matrix pipe 47 %, vector issue 54 %, TA (16-B Q gathers) 68 % busy, HBM 3.5 TB/s - see DESIGN.md section 4",
+                         "limiter": "power: shader clock 1.84 GHz of 2.4 under MFMA + HBM/L2/LDS traffic; cycle count set by vector issue (matrix pipe 47 %, vector issue 54 %, TA 68 % busy) - see DESIGN.md section 4",
                          "launch_ms": launch_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt},
             "mfma": {"model_flops_per_nt": model_flops_nt, "executed_flops_per_nt": exec_flops_nt,
