@@ -563,6 +563,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         constexpr int c = decltype(cc)::value, i = decltype(ii)::value;
         constexpr int kind = c >> 2, cb = c & 3;       // kind 0: E1, 1: E2, 2: M1, 3: M2
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef RN_EXP_NOHELP      /* ablation: no injection / routing MFMAs (wrong results) */
+        if constexpr (i == 0) { T = z; return; }
+        if constexpr (i > 8) return;
+#endif
         if constexpr (i == 0) {
             if constexpr (kind == 0) inject_p(T, tab.p_e, pwe[cb], cb);
             else if constexpr (kind == 2) inject_p(T, tab.p_m, pwm[cb], cb);
