@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the RNA-MPNN forward hot path on MI355X (contract: see the task brief).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of ``RNAMPNN.forward`` over one batch of synthetic k-NN RNA graphs that
-is already resident in HBM.  At N = 1 the workload is BASELINE.json configs[1]:
-256 RNAs, lengths ~ U[100,140] (mean 120), k = 30, default 10-layer stack, bf16 MFMA kernels.
-With N ranks every rank runs its own batch of that shape (different RNAs; weak scaling, no
-data-path collective: the forward shards by independent RNAs) and ``value`` is the whole-job
-valid-nucleotide throughput: (sum over ranks of valid nt per step) * K / max-over-ranks time.
+A "step" is one pass of ``RNAMPNN.forward`` over one batch of synthetic k-NN RNA graphs that is already
+resident in HBM.
+
+* N = 1: BASELINE.json configs[1] ("C2"): 256 RNAs, lengths ~ U[100,140] (mean 120), k = 30, default
+  10-layer stack, bf16 MFMA kernels.
+* N > 1: BASELINE.json configs[3] ("C4"): 10,000 synthetic RNAs x 200 nt, k = 30, split over the ranks as whole
+  RNAs (``rnampnn.utils.shard.balanced_shards``); a step is one forward pass of every rank over its shard (in
+  micro-batches of <= 2,500 RNAs).  The forward needs NO data-path collective (RNAs are independent units); the
+  one exchange of the path is the gradient all-reduce of a training step, measured as a separate leg
+  (``"train"``: taped forward + HIP backward + ONE flat RCCL all-reduce of 14.15 MB + Adam, as Lightning DDP
+  does for the reference, rnampnn/utils/train.py:106-117).
+  ``value`` = (valid nucleotides all ranks pushed through forward) * K / max-over-ranks time.
+
+Launch: with ``--gpus N > 1`` and no RANK in the environment this script spawns its own N ranks
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py``, as CHILD processes, before anything touches
+the GPU); under an external ``torch.distributed.run`` it reads RANK / LOCAL_RANK / WORLD_SIZE and checks
+WORLD_SIZE == --gpus.  One process per GPU, RCCL ("nccl") for the collectives.
 
 Extra objects on the JSON line:
-  roofline     - the dominant kernel (fused ResMPNN edge kernel): algorithmic HBM bytes per
-                 launch / its mean launch duration, timed live with HIP events on the launch
-                 stream (rnampnn_profile_*), against the 8 TB/s HBM3E peak.
-  cpu_baseline - the CPU oracle (a port of the reference's PyTorch-CPU path, kind "port")
-                 timed on this box's host cores on a bounded sample (16 RNAs of the same
-                 workload), rank 0 at N = 1 only.
+  roofline     - the dominant kernel (fused ResMPNN edge kernel): algorithmic HBM bytes per launch / its mean launch
+                 duration, timed live with HIP events on the launch stream (rnampnn_profile_*), vs 8 TB/s.
+  cpu_baseline - the CPU oracle (a port of the reference's PyTorch-CPU path, kind "port") timed on this box's host
+                 cores on a bounded sample (16 RNAs of the same workload), rank 0 at N = 1 only.
+  train        - the training-step leg (N > 1 by default, ``--train-steps`` elsewhere).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,40 +42,48 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "rna-mpnn_amd"))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3
+C4_RNAS, C4_LEN, C4_MICRO = 10000, 200, 2500
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"])
+    ap.add_argument("--workload", default=None, choices=["c2", "c4"], help="default: c2 at N = 1, c4 at N > 1")
     ap.add_argument("--precision", default=os.environ.get("RNAMPNN_BENCH_PRECISION", "bf16"), choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=0, help="RNAs per step per rank (default: workload's)")
+    ap.add_argument("--batch", type=int, default=0, help="c2: RNAs per step per rank; c4: total RNAs of the job")
     ap.add_argument("--neighbours", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16)
-    return ap.parse_args()
+    ap.add_argument("--train-steps", type=int, default=-1, help="training-step leg (default: 3 at N > 1, 0 at N = 1)")
+    ap.add_argument("--train-batch", type=int, default=64, help="RNAs per rank per training step")
+    ap.add_argument("--no-build", action="store_true",
+                    help="load the prebuilt library only (required under rocprofv3: a hipcc child of a profiled process is a forbidden exec hop)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / reduction plumbing only: no model, no kernels, no GPU (CPU test of the N > 1 path)")
+    return ap.parse_args(argv)
 
 
-def workload(args, rank):
-    from rnampnn.utils import synth
-    if args.workload == "c2":      # BASELINE.json configs[1]
-        B = args.batch or 256
-        lens = synth.synth_lengths(B, 100, 140, seed=0, first_index=rank * B)
-        name = f"C2: batch={B} RNAs, n~U[100,140], k={args.neighbours}, default 10-layer RNAMPNN, P=T"
-    else:                          # configs[3] shape: 200-nt RNAs
-        B = args.batch or 1024
-        lens = np.full(B, 200, dtype=np.int64)
-        name = f"C4-shaped: batch={B} RNAs x 200 nt, k={args.neighbours}, default 10-layer RNAMPNN, P=T"
-    coords, mask, labels = synth.synth_batch(lens, first_index=rank * B, seed=0)
-    return name, lens, coords, mask, labels
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without RANK: start N ranks as children of this (GPU-untouched) process and relay their output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def flops_per_nt(k, n, L=10, skip_dead=True, factored=False):
@@ -77,16 +97,51 @@ def flops_per_nt(k, n, L=10, skip_dead=True, factored=False):
     return k * edge + node
 
 
+def build_workload(args, rank, world):
+    """-> (name, list of (coords, mask, labels) numpy micro-batches of this rank, lengths of this rank's RNAs)."""
+    import numpy as np
+    from rnampnn.utils import shard, synth
+    k = args.neighbours
+    if args.workload == "c2":      # BASELINE.json configs[1]; with N ranks: each its own batch of that shape
+        B = args.batch or 256
+        lens = synth.synth_lengths(B, 100, 140, seed=0, first_index=rank * B)
+        name = f"C2: batch={B} RNAs, n~U[100,140], k={k}, default 10-layer RNAMPNN, P=T"
+        return name, [synth.synth_batch(lens, first_index=rank * B, seed=0)], lens, "weak"
+    total = args.batch or C4_RNAS   # BASELINE.json configs[3]: fixed job, split over the ranks
+    all_lens = [C4_LEN] * total
+    mine = shard.balanced_shards(all_lens, world)[rank]
+    name = (f"C4: {total} RNAs x {C4_LEN} nt, k={k}, default 10-layer RNAMPNN, P=T, whole RNAs sharded over {world} rank(s) "
+            f"(balanced_shards), micro-batches of <= {C4_MICRO} RNAs")
+    batches = []
+    for i in range(0, len(mine), C4_MICRO):
+        ids = mine[i:i + C4_MICRO]
+        coords = np.stack([synth.synth_rna(C4_LEN, j, 0) for j in ids]).astype(np.float32)
+        labels = np.stack([synth.synth_labels(C4_LEN, j, 0) for j in ids])
+        batches.append((coords, np.ones((len(ids), C4_LEN), np.float32), labels))
+    return name, batches, np.full(len(mine), C4_LEN, dtype=np.int64), "strong"
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.workload is None:
+        args.workload = "c2" if world == 1 else "c4"
     # rehearsal knobs (not used by the driver): RNAMPNN_BENCH_BACKEND=gloo and RNAMPNN_BENCH_ONE_GPU=1 let the
     # N>1 path run with every rank on GPU 0 of a one-GPU box
     backend = os.environ.get("RNAMPNN_BENCH_BACKEND", "nccl")
     if os.environ.get("RNAMPNN_BENCH_ONE_GPU") == "1":
         local = 0
+    dry = args.dry_run
+    if dry:
+        backend = "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -94,67 +149,78 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the two scalar reductions live
-
-    import __graft_entry__ as g
-    if world > 1:                       # one builder per node; the others load the finished library
-        import torch.distributed as dist
-        if local == 0:
-            g.build()
-        dist.barrier()
-    g.build()
-    from rnampnn.model.rnampnn import RNAMPNN, argmax_recovery
-    from rnampnn.utils import synth
-
-    name, lens, coords, mask, labels = workload(args, rank)
-    T = int(mask.shape[1])
-    k = args.neighbours
-    hp = dict(num_res_neighbours=k, padding_len=T)
-    model = RNAMPNN(precision=args.precision, **hp)
-    sd = synth.closed_form_state_dict({kk: tuple(v.shape) for kk, v in model.state_dict().items()})
-    model.load_state_dict({kk: torch.from_numpy(v) for kk, v in sd.items()})
-    model = model.to(dev).eval()
-    c = torch.from_numpy(coords).to(dev)
-    m = torch.from_numpy(mask).to(dev)
-    lab = torch.from_numpy(labels).to(dev)
-    nt_rank = int(lens.sum())
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")     # where the scalar reductions live
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    import __graft_entry__ as g
+    no_build = args.no_build or os.environ.get("RNAMPNN_NO_BUILD") == "1"
+    if world > 1 and not no_build:      # one builder per node; the others load the finished library
+        if local == 0 or os.environ.get("RNAMPNN_BENCH_ONE_GPU") == "1" and rank == 0:
+            g.build()
+        import torch.distributed as dist
+        dist.barrier()
+    g.load_only() if (no_build or world > 1) else g.build()
+    from rnampnn.utils import synth, shard
+
+    name, batches, lens, scaling = build_workload(args, rank, world)
+    T = int(batches[0][1].shape[1])
+    k = args.neighbours
+    hp = dict(num_res_neighbours=k, padding_len=T)
+    nt_rank = int(lens.sum())
+    model = None
+    if not dry:
+        from rnampnn.model.rnampnn import RNAMPNN, argmax_recovery
+        model = RNAMPNN(precision=args.precision, **hp)
+        sd = synth.closed_form_state_dict({kk: tuple(v.shape) for kk, v in model.state_dict().items()})
+        model.load_state_dict({kk: torch.from_numpy(v) for kk, v in sd.items()})
+        model = model.to(dev).eval()
+    dev_batches = [(torch.from_numpy(c).to(dev), torch.from_numpy(m).to(dev), torch.from_numpy(y).to(dev)) for c, m, y in batches]
+
+    def step():
+        out = None
+        for c, m, _ in dev_batches:
+            out = model(c, m) if model is not None else None
+        return out
 
     for _ in range(args.warmup):
-        logits = model(c, m)
-    model.profile_enable(True, every=7)     # sampled: 7 is coprime to the 10 fused launches of a forward, so every layer gets timed
-    model.profile_read(reset=True)
+        logits = step()
+    if model is not None:
+        model.profile_enable(True, every=7)     # sampled: 7 is coprime to the 10 fused launches of a forward, so every layer gets timed
+        model.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        logits = model(c, m)
-    torch.cuda.synchronize(dev)
+        logits = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms, launches = model.profile_read(reset=True)
-    model.profile_enable(False)
+    kern_ms, launches = (0.0, 0)
+    if model is not None:
+        kern_ms, launches = model.profile_read(reset=True)
+        model.profile_enable(False)
 
-    nt_total, t_max = float(nt_rank), elapsed
-    if world > 1:
-        import torch.distributed as dist
-        buf = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
-        t_max = float(buf[0])
-        cnt = torch.tensor([nt_rank], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        nt_total = float(cnt[0])
+    t_max, nt_total = shard.reduce_job(elapsed, float(nt_rank), red_dev)
     value = nt_total * args.steps / t_max
 
-    # recovery of the GPU path on its batch (synthetic labels, closed-form weights)
-    _, correct, nvalid = argmax_recovery(logits, m, lab)
-    rec_gpu = float(correct.sum()) / float(nvalid.sum())
+    rec_gpu = None
+    if model is not None:       # recovery of the GPU path on its last micro-batch (synthetic labels, closed-form weights)
+        _, correct, nvalid = argmax_recovery(logits, dev_batches[-1][1], dev_batches[-1][2])
+        rec_gpu = float(correct.sum()) / float(nvalid.sum())
+
+    train = None
+    n_train = args.train_steps if args.train_steps >= 0 else (3 if world > 1 else 0)
+    if n_train > 0:
+        train = train_leg(args, model, dev_batches, n_train, world, dev, red_dev, barrier, dry)
 
     if rank == 0:
         n_mean = float(lens.mean())
@@ -167,39 +233,47 @@ def main():
         bytes_first = k * (128 * w + 4) + 256 * 4 + 2 * 128 * 4            # layer 1: message only, reads e once
         bytes_launch_nt = (bytes_first + (L - 1) * bytes_mid) / L           # mean over the L launches of a forward
         launch_ms = kern_ms / max(launches, 1)
+        nt_call = nt_rank / len(batches)                                    # nucleotides one launch works on
+        measured_cfg = args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch and world == 1
         traffic = None                  # HBM bytes per launch from PMC counters, when a profile of this workload is committed
         try:
             prof = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-            if args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch:
+            if measured_cfg:
                 traffic = prof["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        achieved_gbs = bytes_launch_nt * nt_rank / (launch_ms * 1e-3) / 1e9 if launches else 0.0
+        achieved_gbs = bytes_launch_nt * nt_call / (launch_ms * 1e-3) / 1e9 if launches else 0.0
         exec_flops_nt = flops_per_nt(k, n_mean, factored=True)
         model_flops_nt = flops_per_nt(k, n_mean)
         per_rank_rate = nt_rank * args.steps / elapsed
+        roof = {"bound": "hbm", "kernel": "fused ResMPNN edge kernel (k_mpnn_*)",
+                "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "launch_ms": launch_ms, "launches_timed": launches,
+                "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt, "nucleotides_per_launch": nt_call}
+        if measured_cfg:    # these notes were measured on exactly this configuration (profiles/)
+            roof["traffic_note"] = "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_traffic.json"
+            roof["limiter"] = ("power: shader clock 1.84 GHz of 2.4 under MFMA + HBM/L2/LDS traffic; cycle count set by vector issue "
+                               "(matrix pipe 47 %, vector issue 54 %, TA 68 % busy) - profiles/r01_pmc_k_mpnn_bf16_v3.txt, DESIGN.md section 4")
         out = {
             "metric": "nucleotides/sec (forward), k=30 RNA graphs",
             "value": value, "unit": "nucleotides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" if not dry else "dry-run: no kernels launched (launcher test)",
             "config": {"workload": name, "max_len": T, "nucleotides_per_step_per_gpu": nt_rank,
                        "weights": "closed-form deterministic init (3,536,900 params)", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fused ResMPNN edge kernel (k_mpnn_*)",
-                         "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_traffic.json",
-                         "limiter": "power: shader clock 1.84 GHz of 2.4 under MFMA + HBM/L2/LDS traffic; cycle count set by vector issue (matrix pipe 47 %, vector issue 54 %, TA 68 % busy) - see DESIGN.md section 4",
-                         "launch_ms": launch_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt},
+            "roofline": roof,
             "mfma": {"model_flops_per_nt": model_flops_nt, "executed_flops_per_nt": exec_flops_nt,
                      "model_tflops": model_flops_nt * per_rank_rate / 1e12,
                      "executed_tflops": exec_flops_nt * per_rank_rate / 1e12,
                      "peak_tflops": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS},
             "recovery": {"gpu_micro": rec_gpu},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, hp, sd, coords, mask, labels, lens, logits, out)
+        if train is not None:
+            out["train"] = train
+        if world == 1 and not args.no_cpu_baseline and not dry:
+            c0, m0, y0 = batches[0]
+            out["cpu_baseline"] = cpu_baseline(args, hp, sd, c0, m0, y0, lens, logits, out)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -207,8 +281,62 @@ def main():
         dist.destroy_process_group()
 
 
+def train_leg(args, model, dev_batches, n_steps, world, dev, red_dev, barrier, dry):
+    """Training step of the path on ``--train-batch`` RNAs per rank: taped forward + HIP backward (f32) -> ONE flat
+    all-reduce of the gradient buffer (RCCL) -> Adam (reference optimiser, rnampnn.py:156-159).  Aggregate nt/s."""
+    import torch
+    from rnampnn.utils import shard
+    c, m, y = dev_batches[0]
+    nb = min(args.train_batch, int(c.shape[0]))
+    c, m, y = c[:nb].contiguous(), m[:nb].contiguous(), y[:nb].contiguous()
+    nt = float(m.sum())
+    ar_ms = 0.0
+    if dry:
+        flat = torch.zeros(3536900)
+        tr = None
+    else:
+        from rnampnn.model.rnampnn import RNAMPNN
+        tr = RNAMPNN(precision="f32", **{kk: model.hparams[kk] for kk in ("num_res_neighbours", "padding_len")}).to(dev)
+        tr.load_state_dict(model.state_dict())
+        (opt,), _ = tr.configure_optimizers()
+
+    def one():
+        nonlocal ar_ms
+        if dry:
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(flat)
+            return
+        tr.loss_and_grad(y, c, m)
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tr.allreduce_gradients()
+            e1.record()
+            opt.step()
+            e1.synchronize()
+            ar_ms += e0.elapsed_time(e1)
+        else:
+            opt.step()
+
+    one()                                   # warm-up (workspace, RCCL channels)
+    ar_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        one()
+    barrier()
+    el = time.perf_counter() - t0
+    t_max, nt_total = shard.reduce_job(el, nt, red_dev)
+    return {"value": nt_total * n_steps / t_max, "unit": "nucleotides/s (training step: fwd + bwd + all-reduce + Adam)",
+            "steps": n_steps, "ms_per_step": t_max / n_steps * 1e3, "rnas_per_rank_per_step": nb, "dtype": "f32",
+            "allreduce_ms_per_step": ar_ms / n_steps if world > 1 else None, "allreduce_bytes": 3536900 * 4}
+
+
 def cpu_baseline(args, hp, sd, coords, mask, labels, lens, gpu_logits, out):
     """Time the CPU oracle (port of the reference's PyTorch-CPU path) on the first ``cpu_sample`` RNAs."""
+    import numpy as np
+    import torch
     from oracle import rnampnn_oracle as O
     from rnampnn.model._schema import DEFAULT_HPARAMS
     S = min(args.cpu_sample, len(lens))

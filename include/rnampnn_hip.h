@@ -165,19 +165,35 @@ int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, i
                             int32_t n_samples, const uint64_t* seed_device, int8_t* out, void* stream);
 
 /* -- training ---------------------------------------------------------------------------- */
-/* RNAMPNN.training_step up to loss.backward() (rnampnn.py:187-207, loss rnampnn.py:151-154):
- * forward, loss = cross_entropy(softmax(logits)[valid], label) (softmax twice, mean over valid
- * nucleotides) and the gradient of EVERY parameter, f32 kernels, dropout not applied.
- *   labels (B,T) int32 class ids (ignored on padding); loss: device scalar; logits (B,T,4) optional;
- *   grad: flat f32 buffer of rnampnn_grad_numel() elements (overwritten); parameter i of
- *   rnampnn_weight_info() lies at rnampnn_weight_offset(i) - one buffer = one RCCL all-reduce
- *   (what Lightning DDP does for the reference, rnampnn/utils/train.py:106-117). */
+/* The training surface of RNAMPNN (rnampnn.py:187-207 + Lightning's loss.backward()), f32 kernels:
+ *   rnampnn_train_forward  - `self(coords, mask)` in train mode.  Dropout with probability `dropout` after every GELU
+ *       (mpnn.py:140,150; feature.py:200; functional.py:69,124,184) and on the attention probabilities
+ *       (nn.MultiheadAttention(dropout=...), functional.py:109).  The reference draws its masks from torch's global RNG;
+ *       here the keep decision of an element is a pure function of (seed, site, element index) - a 64-bit counter hash
+ *       restated by oracle/rnampnn_oracle.py - so a step is reproducible and testable against autograd.  The
+ *       activations the backward needs (the "tape") stay in `workspace`, which must be left untouched until
+ *       rnampnn_train_backward has run.  logits (B,T,4) out.
+ *   rnampnn_train_backward - gradient of every parameter from dlogits (B,T,4) = d loss / d logits of ANY loss the
+ *       caller built on the logits (torch autograd: torch.autograd.Function in rnampnn/model/rnampnn.py).
+ *       accumulate = 0 overwrites `grad`, 1 adds to it.
+ *   rnampnn_loss_and_grad  - both in one call around the reference loss: cross_entropy(softmax(logits)[valid], label)
+ *       (softmax twice, rnampnn.py:151-154), mean over valid nucleotides.  labels (B,T) int32 class ids (ignored on
+ *       padding); loss: device scalar; logits optional; grad overwritten.
+ *   grad: flat f32 buffer of rnampnn_grad_numel() elements; parameter i of rnampnn_weight_info() lies at
+ *   rnampnn_weight_offset(i) - one buffer = ONE RCCL all-reduce per step (what Lightning DDP does for the reference,
+ *   rnampnn/utils/train.py:106-117).  Every cross-workgroup sum of the backward is an ordered two-stage reduction (no
+ *   float atomics): the same inputs give bit-identical gradients. */
 size_t  rnampnn_train_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
 int64_t rnampnn_grad_numel(rnampnn_handle h);
 int     rnampnn_weight_offset(rnampnn_handle h, int32_t i, int64_t* offset);
-int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float* mask, const int32_t* labels,
-                              int32_t B, int32_t T, int32_t T_norm, float* loss, float* logits, float* grad,
+int     rnampnn_train_forward(rnampnn_handle h, const float* coords, const float* mask, int32_t B, int32_t T,
+                              int32_t T_norm, float dropout, uint64_t seed, float* logits,
                               void* workspace, size_t workspace_bytes, void* stream);
+int     rnampnn_train_backward(rnampnn_handle h, const float* dlogits, int32_t B, int32_t T, int32_t accumulate,
+                               float* grad, void* workspace, size_t workspace_bytes, void* stream);
+int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float* mask, const int32_t* labels,
+                              int32_t B, int32_t T, int32_t T_norm, float dropout, uint64_t seed, float* loss,
+                              float* logits, float* grad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* -- measurement ------------------------------------------------------------------------- */
 /* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when

@@ -54,6 +54,76 @@ class OracleConfig:
     num_readout_layers: int = 2
 
 
+# ----------------------------------------------------------------------------- dropout (train mode)
+# The reference applies nn.Dropout(p) after every GELU (mpnn.py:140,150; feature.py:200; functional.py:69,124,184)
+# and dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), functional.py:109), with masks from
+# torch's global RNG.  The HIP training path draws the keep decision of an element from a counter hash of
+# (seed, site, element index) instead (csrc/kernels_train.h: TDrop); this class restates that hash so oracle autograd
+# and the HIP backward see the same masks.  element index = row * D + channel, rows in the packed order of the valid
+# residues (node row p = cu[b] + t, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
+SITE_EE, SITE_EMB_FFN, SITE_EMB_ATT, SITE_POST_FFN, SITE_POST_ATT, SITE_RAW, SITE_RO = 1, 10, 20, 30, 40, 50, 60
+
+
+def site_msg(layer: int, i: int) -> int:
+    return 100 + 4 * layer + i
+
+
+def site_edge(layer: int, i: int) -> int:
+    return 102 + 4 * layer + i
+
+
+def dropout_multiplier(seed: int, site: int, idx, p: float):
+    """-> float32 numpy array of 0 or 1/(1-p) for the element indices ``idx`` (any integer array)."""
+    import numpy as np
+    m64 = (1 << 64) - 1
+    with np.errstate(over="ignore"):
+        x = (np.asarray(idx).astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        x = x + np.uint64((int(seed) + int(site) * 0xD6E8FEB86659FD93) & m64)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    thresh = int(np.float32(p) * np.float32(16777216.0))
+    keep = (x >> np.uint64(40)).astype(np.int64) >= thresh
+    return np.where(keep, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
+
+
+class Drop:
+    """Dropout context of one forward: p, seed and the packed row of every (b, t)."""
+
+    def __init__(self, p: float, seed: int, mask: Tensor):
+        self.p, self.seed = float(p), int(seed)
+        n = mask.sum(-1).long()
+        cu = torch.cumsum(n, 0) - n
+        t = torch.arange(mask.shape[1]).unsqueeze(0)
+        self.rows = torch.where(mask > 0, cu.unsqueeze(1) + t, torch.zeros_like(t))      # (B,T); padded rows: don't care
+
+    def nodes(self, x: Tensor, site: int) -> Tensor:           # x (B,T,D)
+        if self.p <= 0.0:
+            return x
+        D = x.shape[-1]
+        idx = self.rows.unsqueeze(-1) * D + torch.arange(D)
+        return x * torch.from_numpy(dropout_multiplier(self.seed, site, idx.numpy(), self.p)).to(x.dtype)
+
+    def edges(self, x: Tensor, site: int) -> Tensor:           # x (B,T,k,D)
+        if self.p <= 0.0:
+            return x
+        k, D = x.shape[2], x.shape[3]
+        er = self.rows.unsqueeze(-1) * k + torch.arange(k)
+        idx = er.unsqueeze(-1) * D + torch.arange(D)
+        return x * torch.from_numpy(dropout_multiplier(self.seed, site, idx.numpy(), self.p)).to(x.dtype)
+
+    def attention(self, att: Tensor, site: int) -> Tensor:     # att (B,H,T,T) probabilities
+        if self.p <= 0.0:
+            return att
+        H, T = att.shape[1], att.shape[3]
+        q = self.rows.view(-1, 1, att.shape[2], 1) * H + torch.arange(H).view(1, H, 1, 1)
+        idx = q * 8192 + torch.arange(T).view(1, 1, 1, T)
+        return att * torch.from_numpy(dropout_multiplier(self.seed, site, idx.numpy(), self.p)).to(att.dtype)
+
+    def apply(self, x: Tensor, site: int) -> Tensor:
+        return self.edges(x, site) if x.dim() == 4 else self.nodes(x, site)
+
+
 # ----------------------------------------------------------------------------- helpers
 def _gelu(x: Tensor) -> Tensor:
     # nn.GELU() default = exact erf form (mpnn.py:139,149; functional.py:68,123,183)
@@ -64,17 +134,21 @@ def _linear(x: Tensor, sd: Mapping[str, Tensor], prefix: str) -> Tensor:
     return x @ sd[prefix + ".weight"].T + sd[prefix + ".bias"]
 
 
-def _mlp_all_gelu(x: Tensor, sd, prefix: str, depth: int) -> Tensor:
+def _mlp_all_gelu(x: Tensor, sd, prefix: str, depth: int, drop: Optional["Drop"] = None, site0: int = 0) -> Tensor:
     """Sequential(Linear, GELU, Dropout) x depth - ends in GELU (feature.py:195-203, mpnn.py:135-152)."""
     for i in range(depth):
         x = _gelu(_linear(x, sd, f"{prefix}.{3 * i}"))
+        if drop is not None:
+            x = drop.apply(x, site0 + i)
     return x
 
 
-def _ffn_last_plain(x: Tensor, sd, prefix: str, n_hidden: int) -> Tensor:
+def _ffn_last_plain(x: Tensor, sd, prefix: str, n_hidden: int, drop: Optional["Drop"] = None, site0: int = 0) -> Tensor:
     """n_hidden x (Linear, GELU, Dropout) + final plain Linear (functional.py:119-127,179-187)."""
     for i in range(n_hidden):
         x = _gelu(_linear(x, sd, f"{prefix}.{3 * i}"))
+        if drop is not None:
+            x = drop.apply(x, site0 + i)
     return _linear(x, sd, f"{prefix}.{3 * n_hidden}")
 
 
@@ -191,7 +265,7 @@ def edge_raw_features(coords: Tensor, mask: Tensor, edge_index: Tensor) -> Tenso
 
 # ----------------------------------------------------------------------------- A13
 def rnabert(h: Tensor, mask: Tensor, sd, prefix: str, n_attn: int, n_heads: int,
-            n_ffn: int, padding_len: int) -> Tensor:
+            n_ffn: int, padding_len: int, drop: Optional["Drop"] = None, site_att0: int = 0, site_ffn0: int = 0) -> Tensor:
     """RNABert.forward (functional.py:153-172).  The reference zero-pads to ``padding_len`` P;
     padded keys are masked out of the softmax and padded queries are discarded, so only the
     GraphNormalization sees P (its T_tot).  Computed here on the T valid-capable rows with the
@@ -212,11 +286,13 @@ def rnabert(h: Tensor, mask: Tensor, sd, prefix: str, n_attn: int, n_heads: int,
         v = v.view(B, T, n_heads, hd).transpose(1, 2)
         att = torch.softmax(q @ kx.transpose(-1, -2) + key_bias, dim=-1)
         att = torch.nan_to_num(att, nan=0.0)          # rows of an all-padding RNA (no valid key)
+        if drop is not None:
+            att = drop.attention(att, site_att0 + j)  # nn.MultiheadAttention(dropout=p): on the probabilities (functional.py:109)
         o = (att @ v).transpose(1, 2).reshape(B, T, D)
         x = x + (o @ sd[p + ".out_proj.weight"].T + sd[p + ".out_proj.bias"])     # :165
         g = f"{prefix}.graph_norm_layers.{j}"
         x = _graph_norm_ttot(x, m, sd[g + ".scale"], sd[g + ".shift"], padding_len)  # :169
-    x = _ffn_last_plain(x, sd, f"{prefix}.ffn_layers", n_ffn)           # :170
+    x = _ffn_last_plain(x, sd, f"{prefix}.ffn_layers", n_ffn, drop, site_ffn0)   # :170
     return x * m.unsqueeze(-1)                                          # :171-172
 
 
@@ -236,18 +312,18 @@ def _graph_norm_ttot(x: Tensor, m: Tensor, scale: Tensor, shift: Tensor, t_tot: 
 
 
 # ----------------------------------------------------------------------------- A1-A7
-def res_feature(coords: Tensor, mask: Tensor, sd, cfg: OracleConfig
+def res_feature(coords: Tensor, mask: Tensor, sd, cfg: OracleConfig, drop: Optional["Drop"] = None
                 ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """ResFeature.forward (feature.py:573-592) -> (raw, h0, e0, edge_index)."""
     idx = knn_graph(coords, mask, cfg.num_res_neighbours)
     x = edge_raw_features(coords, mask, idx)
-    e = _mlp_all_gelu(x, sd, "res_feature.res_edge_embedding_layers", cfg.depth_res_edge_feature)
+    e = _mlp_all_gelu(x, sd, "res_feature.res_edge_embedding_layers", cfg.depth_res_edge_feature, drop, SITE_EE)
     e = e.masked_fill((idx == -1).unsqueeze(-1), 0.0)                   # :564-568
     e = e.masked_fill((mask == 0).view(*mask.shape, 1, 1), 0.0)         # :569
     raw = node_raw_features(coords, mask)
     h = _linear(raw, sd, "res_feature.raw_project")                     # :536
     h = rnabert(h, mask, sd, "res_feature.res_embedding", cfg.num_embedding_attn_layers,
-                cfg.num_embedding_heads, cfg.num_embedding_ffn_layers, cfg.padding_len)
+                cfg.num_embedding_heads, cfg.num_embedding_ffn_layers, cfg.padding_len, drop, SITE_EMB_ATT, SITE_EMB_FFN)
     h = graph_norm(h, mask, sd["res_feature.graph_norm.scale"], sd["res_feature.graph_norm.shift"])  # :591
     return raw, h, e, idx
 
@@ -259,12 +335,13 @@ def _gather_nodes(h: Tensor, idx: Tensor) -> Tensor:
     return h[bidx, idx.clamp(min=0)]                                    # -1 -> row 0 (mpnn.py:173-181)
 
 
-def mpnn_message(h: Tensor, e: Tensor, idx: Tensor, mask: Tensor, sd, prefix: str, depth: int) -> Tensor:
+def mpnn_message(h: Tensor, e: Tensor, idx: Tensor, mask: Tensor, sd, prefix: str, depth: int,
+                 drop: Optional["Drop"] = None, site0: int = 0) -> Tensor:
     """ResMPNN.message (mpnn.py:154-194)."""
     h = h * mask.unsqueeze(-1).to(h.dtype)
     k = idx.shape[-1]
     x = torch.cat([h.unsqueeze(2).expand(-1, -1, k, -1), _gather_nodes(h, idx), e], dim=-1)
-    msg = _mlp_all_gelu(x, sd, prefix + ".message_layers", depth)
+    msg = _mlp_all_gelu(x, sd, prefix + ".message_layers", depth, drop, site0)
     return msg * (idx != -1).unsqueeze(-1).to(h.dtype)
 
 
@@ -275,59 +352,64 @@ def mpnn_aggregate(h: Tensor, msg: Tensor, idx: Tensor, mask: Tensor) -> Tensor:
     return (h + msg.sum(dim=2) / cnt) * mask.unsqueeze(-1).to(h.dtype)
 
 
-def mpnn_update_edges(h: Tensor, e: Tensor, idx: Tensor, sd, prefix: str, depth: int) -> Tensor:
+def mpnn_update_edges(h: Tensor, e: Tensor, idx: Tensor, sd, prefix: str, depth: int,
+                      drop: Optional["Drop"] = None, site0: int = 0) -> Tensor:
     """ResMPNN._update_edges (mpnn.py:229-265): residual, NOT masked."""
     k = idx.shape[-1]
     x = torch.cat([h.unsqueeze(2).expand(-1, -1, k, -1), _gather_nodes(h, idx), e], dim=-1)
-    return e + _mlp_all_gelu(x, sd, prefix + ".edge_layers", depth)
+    return e + _mlp_all_gelu(x, sd, prefix + ".edge_layers", depth, drop, site0)
 
 
 def mpnn_layer(h: Tensor, e: Tensor, idx: Tensor, mask: Tensor, sd, layer: int, cfg: OracleConfig,
-               update_edges: bool = True) -> Tuple[Tensor, Tensor]:
+               update_edges: bool = True, drop: Optional["Drop"] = None) -> Tuple[Tensor, Tensor]:
     """ResMPNN.forward (mpnn.py:283-294)."""
     p = f"res_mpnn_layers.{layer}"
-    msg = mpnn_message(h, e, idx, mask, sd, p, cfg.depth_res_mpnn)
+    msg = mpnn_message(h, e, idx, mask, sd, p, cfg.depth_res_mpnn, drop, site_msg(layer, 0))
     h = mpnn_aggregate(h, msg, idx, mask)
     h = graph_norm(h, mask, sd[p + ".graph_norm.scale"], sd[p + ".graph_norm.shift"])
     if update_edges:
-        e = mpnn_update_edges(h, e, idx, sd, p, cfg.num_mpnn_edge_layers)
+        e = mpnn_update_edges(h, e, idx, sd, p, cfg.num_mpnn_edge_layers, drop, site_edge(layer, 0))
     return h, e
 
 
 # ----------------------------------------------------------------------------- A14-A16
-def raw_ffn(raw: Tensor, mask: Tensor, sd, cfg: OracleConfig) -> Tensor:
+def raw_ffn(raw: Tensor, mask: Tensor, sd, cfg: OracleConfig, drop: Optional["Drop"] = None) -> Tensor:
     """RawFFN.forward (functional.py:200-202)."""
-    x = _ffn_last_plain(raw, sd, "raw_embedding.raw_ffn", cfg.num_raw_ffn_layers)
+    x = _ffn_last_plain(raw, sd, "raw_embedding.raw_ffn", cfg.num_raw_ffn_layers, drop, SITE_RAW)
     return graph_norm(x, mask, sd["raw_embedding.graph_norm.scale"], sd["raw_embedding.graph_norm.shift"])
 
 
-def readout(x: Tensor, mask: Tensor, sd, cfg: OracleConfig) -> Tensor:
+def readout(x: Tensor, mask: Tensor, sd, cfg: OracleConfig, drop: Optional["Drop"] = None) -> Tensor:
     """Readout.forward (functional.py:86-90)."""
     for i in range(cfg.num_readout_layers - 1):
         x = _gelu(_linear(x, sd, f"readout.readout_layers.{3 * i}"))
+        if drop is not None:
+            x = drop.nodes(x, SITE_RO + i)
     x = _linear(x, sd, f"readout.readout_layers.{3 * (cfg.num_readout_layers - 1)}")
     return x * mask.unsqueeze(-1).to(x.dtype)
 
 
 def forward(coords: Tensor, mask: Tensor, sd, cfg: OracleConfig, taps: Optional[dict] = None,
-            skip_dead_edge_update: bool = True) -> Tuple[Tensor, Tensor]:
+            skip_dead_edge_update: bool = True, dropout: float = 0.0, seed: int = 0) -> Tuple[Tensor, Tensor]:
     """RNAMPNN.forward + embedding (rnampnn.py:173-185, 269-278) -> (logits (B,T,4), embedding (B,T,256)).
-    ``taps`` (a dict) receives named intermediates when given."""
-    raw, h, e, idx = res_feature(coords, mask, sd, cfg)
+    ``taps`` (a dict) receives named intermediates when given.  ``dropout`` > 0: train-mode forward with the
+    counter-hash masks of ``Drop`` (eval mode, the default, is what the golden fixtures pin)."""
+    drop = Drop(dropout, seed, mask) if dropout > 0.0 else None
+    raw, h, e, idx = res_feature(coords, mask, sd, cfg, drop)
     if taps is not None:
         taps.update(raw=raw, h0=h, e0=e, edge_index=idx)
     L = cfg.num_res_mpnn_layers
     for l in range(L):
         dead = skip_dead_edge_update and l == L - 1 and taps is None   # layer-L edge update is never consumed
-        h, e = mpnn_layer(h, e, idx, mask, sd, l, cfg, update_edges=not dead)
+        h, e = mpnn_layer(h, e, idx, mask, sd, l, cfg, update_edges=not dead, drop=drop)
         if taps is not None:
             taps[f"h{l + 1}"] = h
             taps[f"e{l + 1}"] = e
     hp = rnabert(h, mask, sd, "post_fusion", cfg.num_post_fusion_attn_layers, cfg.num_post_fusion_heads,
-                 cfg.num_post_fusion_ffn_layers, cfg.padding_len)
-    re = raw_ffn(raw, mask, sd, cfg)
+                 cfg.num_post_fusion_ffn_layers, cfg.padding_len, drop, SITE_POST_ATT, SITE_POST_FFN)
+    re = raw_ffn(raw, mask, sd, cfg, drop)
     emb = torch.cat((hp, re), dim=-1)
-    logits = readout(emb, mask, sd, cfg)
+    logits = readout(emb, mask, sd, cfg, drop)
     if taps is not None:
         taps.update(h_post=hp, raw_emb=re, embedding=emb, logits=logits)
     return logits, emb

@@ -93,6 +93,12 @@ struct rnampnn_ctx {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     long long prof_n = 0;
+    // tape of the last rnampnn_train_forward (the activations themselves live in the caller's workspace)
+    bool tape_valid = false;
+    int tape_B = 0, tape_T = 0, tape_tnorm = 0;
+    float tape_p = 0.f;
+    uint64_t tape_seed = 0;
+    const void* tape_ws = nullptr;
 };
 
 static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {

@@ -808,16 +808,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #undef RN_FRAG
 }
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int num_cus() { return rn_num_cus(); }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
@@ -839,11 +830,8 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     const bool smallk = k <= 16, mo = msg_out != nullptr;
 #define RN_LAUNCH(E, M, S, O)                                                                                  \
     do {                                                                                                       \
-        static bool done = false;                                                                              \
-        if (!done) {                                                                                           \
-            (void)hipFuncSetAttribute((const void*)k_mpnn_bf16<E, M, S, O>, hipFuncAttributeMaxDynamicSharedMemorySize, RN_MPNN_LDS); \
-            done = true;                                                                                       \
-        }                                                                                                      \
+        static DevAttr attr;                                                                                   \
+        ensure_dyn_lds((const void*)k_mpnn_bf16<E, M, S, O>, RN_MPNN_LDS, attr);                               \
         hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(RN_MPNN_WAVES * 64), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
     } while (0)
     if (do_edge && do_msg) { if (smallk) RN_LAUNCH(true, true, true, false); else RN_LAUNCH(true, true, false, false); }
@@ -1291,8 +1279,8 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
     const size_t lds = CH_RING * 32768 + (size_t)((NH + 1) * H + NOUT) * sizeof(float);
 #define RN_CHAIN(k0, hh, nh, no) \
     if (K0 == k0 && H == hh && NH == nh && NOUT == no) { \
-        static bool done = false; \
-        if (!done) { (void)hipFuncSetAttribute((const void*)k_ffn_chain<k0, hh, nh, no>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; } \
+        static DevAttr attr; \
+        ensure_dyn_lds((const void*)k_ffn_chain<k0, hh, nh, no>, lds, attr); \
         hipLaunchKernelGGL((k_ffn_chain<k0, hh, nh, no>), grid, dim3(256), lds, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; }
     RN_CHAIN(128, 512, 2, 128)
     RN_CHAIN(32, 512, 2, 128)
@@ -1493,12 +1481,9 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     PqJob j0{img0, bias0, p0, q0}, j1{img1, bias1, p1, q1};
     dim3 grid((pk.Nmax + 127) / 128);
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)k_node_update<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
-        (void)hipFuncSetAttribute((const void*)k_node_update<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024);
-        done = true;
-    }
+    static DevAttr attr1, attr2;
+    ensure_dyn_lds((const void*)k_node_update<1>, 65536 + 1024, attr1);
+    ensure_dyn_lds((const void*)k_node_update<2>, 131072 + 1024, attr2);
     const float* cf = scale ? coef : nullptr;
     if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536 + 1024, s, pk, x, add, cf, h_out, j0, j1);
     else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072 + 1024, s, pk, x, add, cf, h_out, j0, j1);
@@ -1606,11 +1591,8 @@ int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float
     const int nkb = (pk.T + 31) / 32;
     const size_t lds = (size_t)nkb * 64 * 16 * 2;
     if (lds > 150 * 1024) return 1;
-    static size_t attr = 0;
-    if (lds > 65536 && lds > attr) {
-        (void)hipFuncSetAttribute((const void*)k_attention_bf16_hd16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    static DevAttr attr;
+    ensure_dyn_lds((const void*)k_attention_bf16_hd16, lds, attr);
     hipLaunchKernelGGL(k_attention_bf16_hd16, dim3(pk.B, heads), dim3(512), lds, s, pk, qkv, out);
     return 0;
 }

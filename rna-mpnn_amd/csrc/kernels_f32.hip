@@ -50,10 +50,34 @@ __global__ void __launch_bounds__(1024) k_scan(const int* __restrict__ len, int 
     for (int i = lo; i < hi; ++i) { cu[i] = run; run += len[i]; }
 }
 
-__global__ void k_lengths_from_cu(const int32_t* __restrict__ cu_in, int B, int* __restrict__ len, int* __restrict__ cu) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) len[b] = cu_in[b + 1] - cu_in[b];
-    if (b <= B) cu[b] = cu_in[b] - cu_in[0];
+// Packed input: lengths and the internal prefix sum from the caller's cu_seqlens.  The caller's contract is
+// 0 <= cu[b+1] - cu[b] <= T_max and cu[B] - cu[0] == N_total; a violation must not become an out-of-bounds access
+// (k_knn sizes LDS rows by T_max, the workspace is carved for N_total rows), so lengths are clamped to [0, T_max] and the
+// running total to N_total - results for an out-of-contract input are meaningless, but memory-safe.
+__global__ void __launch_bounds__(1024) k_lengths_from_cu(const int32_t* __restrict__ cu_in, int B, int T, int Nmax,
+                                                          int* __restrict__ len, int* __restrict__ cu) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (B + 1023) / 1024;
+    const int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += min(max(cu_in[i + 1] - cu_in[i], 0), T);
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { int v = part[i]; part[i] = run; run += v; }
+        cu[B] = min(run, Nmax);
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        const int l = min(max(cu_in[i + 1] - cu_in[i], 0), T);
+        const int c0 = min(run, Nmax);
+        cu[i] = c0;
+        len[i] = min(l, Nmax - c0);
+        run += l;
+    }
 }
 // zero up to 8 small regions (the all-zero gather rows of the node tables) in one launch
 __global__ void k_zero_regions(ZeroRegions z) {
@@ -67,7 +91,7 @@ void launch_zero_regions(const ZeroRegions& z, hipStream_t s) {
 }
 
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s) {
-    hipLaunchKernelGGL(k_lengths_from_cu, dim3((pk.B + 256) / 256), dim3(256), 0, s, cu_seqlens, pk.B, pk.len, pk.cu);
+    hipLaunchKernelGGL(k_lengths_from_cu, dim3(1), dim3(1024), 0, s, cu_seqlens, pk.B, pk.T, pk.Nmax, pk.len, pk.cu);
 }
 
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s) {
@@ -294,8 +318,8 @@ int launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t
     }
     size_t lds = (size_t)(3 + 4) * pk.T * sizeof(float);
     if (lds > 160 * 1024 - 256) return 1;                       // T too long for the LDS-resident row
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_knn<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DevAttr attr;
+    ensure_dyn_lds((const void*)k_knn<64>, lds, attr);
     int rpb = pk.T <= 512 ? 16 : 64;
     dim3 grid(pk.B, (pk.T + rpb - 1) / rpb);
     hipLaunchKernelGGL(k_knn<64>, grid, dim3(256), lds, s, coords, pk, k, rpb, nbr, eidx);

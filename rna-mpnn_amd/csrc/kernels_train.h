@@ -4,22 +4,50 @@
 
 struct TRows { const int* ntot; int mul; int maxrows; };   // row count = *ntot * mul (device side), maxrows = host upper bound
 
+// Dropout of the training path (the reference: nn.Dropout(p) after every GELU, mpnn.py:140,150, feature.py:200,
+// functional.py:69,124,184, and on the attention probabilities, functional.py:109).  The keep decision of one element is a
+// pure function of (seed, site, element index): a 64-bit counter hash, restated by the CPU oracle, so that the HIP
+// forward / backward and the oracle's autograd see THE SAME mask.  element index = row * D + channel with rows in
+// the packed order (node row p, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
+struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // keep iff hash24 >= thresh (= p * 2^24); scale = 1/(1-p)
+static inline TDrop t_drop(float p, unsigned long long seed) {
+    TDrop d;
+    d.seed = seed;
+    d.thresh = p > 0.f ? (unsigned)(p * 16777216.0f) : 0u;
+    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
+
 void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, int ldw, const float* bias, int N,
             float* Y, int ldy, int beta, hipStream_t s);                      // Y = beta*Y + X.Wt + bias   (Wt K-major, row stride ldw)
-void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw, hipStream_t s);  // dW += A^T B
-void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, hipStream_t s);                // out += column sums
-void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, hipStream_t s);
-void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, hipStream_t s);     // dx = dy * gelu'(pre)
+struct TScratch { float* p; size_t floats; };                // partial results of the ordered two-stage reductions
+void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
+               const TScratch& sc, hipStream_t s);                                                           // dW += A^T B
+void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s);   // out += column sums
+void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, const TDrop& dr, unsigned site, hipStream_t s);   // y = drop(gelu(x))
+void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site,
+                hipStream_t s);                                                                             // dx = dy * mask * gelu'(pre)
 void t_add(const TRows& rows, const float* a, float* dst, int D, hipStream_t s);                            // dst += a
 void t_edge_features(const PackInfo& pk, int k, const float* geom, const int* nbr, float* F, hipStream_t s);        // [E][96]
 void t_edge_add_pq(const PackInfo& pk, int k, const int* nbr, const float* pq, float* pre, hipStream_t s);          // pre += P[i] + Q[j]
 void t_edge_zero_invalid(const PackInfo& pk, int k, const int* nbr, float* x, hipStream_t s);
-void t_edge_residual(const PackInfo& pk, int k, const int* nbr, const float* e_in, const float* pre2, float* e_out, hipStream_t s);
-void t_seg_mean(const PackInfo& pk, int k, const int* nbr, const float* pre2, const float* h, float* out, hipStream_t s);
-void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const float* pre2, float* dpre2, hipStream_t s);
-void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2, hipStream_t s);
-void t_edge_pq_bwd(const PackInfo& pk, int k, const int* nbr, const float* dpre1, float* dpq, hipStream_t s);
+void t_edge_residual(const PackInfo& pk, int k, const int* nbr, const float* e_in, const float* pre2, float* e_out,
+                     const TDrop& dr, unsigned site, hipStream_t s);
+void t_seg_mean(const PackInfo& pk, int k, const int* nbr, const float* pre2, const float* h, float* out,
+                const TDrop& dr, unsigned site, hipStream_t s);
+void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const float* pre2, float* dpre2,
+                    const TDrop& dr, unsigned site, hipStream_t s);
+void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2,
+                    const TDrop& dr, unsigned site, hipStream_t s);
+// reverse adjacency (deg/start/fill: [Nmax+1] ints, list: [Nmax*k] ints) and the gather-form backward of P[i] + Q[j]
+void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, hipStream_t s);
+void t_edge_pq_bwd(const PackInfo& pk, int k, const float* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
-              float* dshift, hipStream_t s);
-int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat, hipStream_t s);
-void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, hipStream_t s);
+              float* dshift, const TScratch& sc, hipStream_t s);
+int  t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, const TDrop& dr, unsigned site, hipStream_t s);
+int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat,
+                     const TDrop& dr, unsigned site, hipStream_t s);
+// loss = mean_valid CE(softmax(logits), label) and d loss / d logits (packed rows)
+void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlogits_p, hipStream_t s);
+void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, const TScratch& sc,
+                 hipStream_t s);

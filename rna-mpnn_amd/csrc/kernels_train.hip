@@ -4,7 +4,7 @@
 // walks the tape with generic row kernels (GEMM, transposed-reduce GEMM, element-wise GELU',
 // segment mean / scatter, GraphNorm and attention backward).  Reference: rnampnn.py:151-154,187-207
 // (loss = cross_entropy(softmax(logits)[valid], label), mean over valid nucleotides) and the forward
-// lines cited in kernels_f32.hip.  Dropout is not applied (p = 0 semantics).
+// lines cited in kernels_f32.hip.  Dropout: counter-hash masks (TDrop, kernels_train.h); every cross-workgroup sum is an ordered two-stage reduction (no float atomics).
 #include "kernels_train.h"
 
 static constexpr float kSEPS = 1.0e-6f;
@@ -15,6 +15,15 @@ __device__ __forceinline__ float gelu_d(float x) {     // d/dx [x Phi(x)] = Phi(
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ int nrows(const TRows& r) { return *r.ntot * r.mul; }
+// dropout multiplier of one element: 0 or 1/(1-p) (kernels_train.h: TDrop; restated by oracle dropout_mask)
+__device__ __forceinline__ float drop_mul(const TDrop& d, unsigned site, unsigned long long idx) {
+    if (d.thresh == 0u) return 1.f;
+    unsigned long long x = (idx + 1ull) * 0x9E3779B97F4A7C15ull + d.seed + (unsigned long long)site * 0xD6E8FEB86659FD93ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (unsigned)(x >> 40) >= d.thresh ? d.scale : 0.f;
+}
 
 // ------------------------------------------------------------------------------------------
 // Y[p][0:N] = (beta ? Y : 0) + X[p][0:K] . Wt[0:K][0:N] + bias      (32 x 128 tile, K % 4 == 0)
@@ -71,14 +80,28 @@ void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, 
     hipLaunchKernelGGL(k_tgemm, grid, dim3(256), 0, s, rows, X, ldx, K, Wt, ldw, bias, N, Y, ldy, beta);
 }
 
-// dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block, row range split over blockIdx.z, f32 atomics)
+// Ordered reduction of partial results: out[(i / cols) * ld_out + i % cols] += sum_{s < nparts} part[s * count + i], s ascending.
+// Every cross-workgroup sum of the backward goes through this (no float atomics): gradients are bit-reproducible.
+__global__ void k_reduce_parts(const float* __restrict__ part, int nparts, size_t stride, int count, int cols,
+                               float* __restrict__ out, int ld_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];
+    out[(size_t)(i / cols) * ld_out + (i % cols)] += s;
+}
+static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out);
+}
+
+// dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block; the row range is split over blockIdx.z, every split
+// writes its own partial tile, k_reduce_parts adds them in split order)
 __global__ void __launch_bounds__(256) k_tgemm_tn(TRows rows, const float* __restrict__ A, int lda, int M,
-        const float* __restrict__ B, int ldb, int K, float* __restrict__ dW, int ldw, int rows_per_split) {
+        const float* __restrict__ B, int ldb, int K, float* __restrict__ part, int rows_per_split) {
     __shared__ float As[32][33], Bs[32][33];
     const int R = nrows(rows);
     const int p_begin = blockIdx.z * rows_per_split;
     const int p_end = min(R, p_begin + rows_per_split);
-    if (p_begin >= p_end) return;
     const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     const int tid = threadIdx.x, tm = tid >> 4, tk = tid & 15;        // thread -> m in {tm, tm+16}, k in {tk, tk+16}
     float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
@@ -97,56 +120,70 @@ __global__ void __launch_bounds__(256) k_tgemm_tn(TRows rows, const float* __res
         }
         __syncthreads();
     }
+    float* dst = part + (size_t)blockIdx.z * M * K;                   // splits beyond the live rows store zeros
     const int mA = m0 + tm, mB = m0 + tm + 16, kA = k0 + tk, kB = k0 + tk + 16;
-    if (mA < M && kA < K) atomicAdd(dW + (size_t)mA * ldw + kA, a00);
-    if (mA < M && kB < K) atomicAdd(dW + (size_t)mA * ldw + kB, a01);
-    if (mB < M && kA < K) atomicAdd(dW + (size_t)mB * ldw + kA, a10);
-    if (mB < M && kB < K) atomicAdd(dW + (size_t)mB * ldw + kB, a11);
+    if (mA < M && kA < K) dst[(size_t)mA * K + kA] = a00;
+    if (mA < M && kB < K) dst[(size_t)mA * K + kB] = a01;
+    if (mB < M && kA < K) dst[(size_t)mB * K + kA] = a10;
+    if (mB < M && kB < K) dst[(size_t)mB * K + kB] = a11;
 }
-void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw, hipStream_t s) {
+void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
+               const TScratch& sc, hipStream_t s) {
+    long long cap = (long long)(sc.floats / ((size_t)M * K));
     int splits = (rows.maxrows + 2047) / 2048;
-    if (splits < 1) splits = 1;
     if (splits > 512) splits = 512;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
     int rps = ((rows.maxrows + splits - 1) / splits + 31) / 32 * 32;
     dim3 grid((M + 31) / 32, (K + 31) / 32, splits);
-    hipLaunchKernelGGL(k_tgemm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, dW, ldw, rps);
+    hipLaunchKernelGGL(k_tgemm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, rps);
+    reduce_parts(sc.p, splits, (size_t)M * K, M * K, K, dW, ldw, s);
 }
 
-// out[m] += sum_p A[p][m]
-__global__ void __launch_bounds__(256) k_colsum(TRows rows, const float* __restrict__ A, int lda, int M, float* __restrict__ out,
+// out[m] += sum_p A[p][m]   (per-block partial rows, ordered reduction)
+__global__ void __launch_bounds__(256) k_colsum(TRows rows, const float* __restrict__ A, int lda, int M, float* __restrict__ part,
                                                  int rows_per_block) {
     const int R = nrows(rows);
     const int p0 = blockIdx.x * rows_per_block, p1 = min(R, p0 + rows_per_block);
     for (int m = threadIdx.x; m < M; m += 256) {
         float s = 0.f;
         for (int p = p0; p < p1; ++p) s += A[(size_t)p * lda + m];
-        if (p0 < p1) atomicAdd(out + m, s);
+        part[(size_t)blockIdx.x * M + m] = s;
     }
 }
-void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, hipStream_t s) {
-    int rpb = 256;
-    hipLaunchKernelGGL(k_colsum, dim3((rows.maxrows + rpb - 1) / rpb), dim3(256), 0, s, rows, A, lda, M, out, rpb);
+void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s) {
+    int nb = (int)(sc.floats / (size_t)M);
+    if (nb > 1024) nb = 1024;
+    int rpb = (rows.maxrows + nb - 1) / nb;
+    if (rpb < 64) rpb = 64;
+    nb = (rows.maxrows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, rows, A, lda, M, sc.p, rpb);
+    reduce_parts(sc.p, nb, (size_t)M, M, M, out, M, s);
 }
 
 // element-wise over rows x D (contiguous, ld = D)
-__global__ void k_gelu_fwd(TRows rows, const float* __restrict__ x, float* __restrict__ y, int D) {
+__global__ void k_gelu_fwd(TRows rows, const float* __restrict__ x, float* __restrict__ y, int D, TDrop dr, unsigned site) {
     const size_t n = (size_t)nrows(rows) * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_f(x[i]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = gelu_f(x[i]) * drop_mul(dr, site, i);
 }
-__global__ void k_gelu_bwd(TRows rows, const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int D) {
+__global__ void k_gelu_bwd(TRows rows, const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int D,
+                           TDrop dr, unsigned site) {
     const size_t n = (size_t)nrows(rows) * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = dy[i] * gelu_d(pre[i]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * gelu_d(pre[i]) * drop_mul(dr, site, i);
 }
 __global__ void k_add(TRows rows, const float* __restrict__ a, float* __restrict__ dst, int D) {
     const size_t n = (size_t)nrows(rows) * D;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += a[i];
 }
 static unsigned ew_grid(const TRows& r, int D) { size_t g = ((size_t)r.maxrows * D + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
-void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, hipStream_t s) {
-    hipLaunchKernelGGL(k_gelu_fwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, x, y, D);
+void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_gelu_fwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, x, y, D, dr, site);
 }
-void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, hipStream_t s) {
-    hipLaunchKernelGGL(k_gelu_bwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, dy, pre, dx, D);
+void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_gelu_bwd, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, dy, pre, dx, D, dr, site);
 }
 void t_add(const TRows& rows, const float* a, float* dst, int D, hipStream_t s) {
     hipLaunchKernelGGL(k_add, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, a, dst, D);
@@ -183,7 +220,8 @@ void t_edge_features(const PackInfo& pk, int k, const float* geom, const int* nb
 
 // mode 0: pre[e] += P[i] + Q[j];  mode 1: x[e] = 0 on invalid slots;  mode 2: dst[e] = src1[e] + (valid ? gelu(src2[e]) : 0)
 __global__ void k_edge_elem(PackInfo pk, int k, const int* __restrict__ nbr, int mode, const float* __restrict__ pq,
-                            float* __restrict__ x, const float* __restrict__ src1, const float* __restrict__ src2) {
+                            float* __restrict__ x, const float* __restrict__ src1, const float* __restrict__ src2,
+                            TDrop dr, unsigned site) {
     const size_t n = (size_t)pk.cu[pk.B] * k * 32;               // float4 units
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(id & 31);
@@ -204,7 +242,9 @@ __global__ void k_edge_elem(PackInfo pk, int k, const int* __restrict__ nbr, int
             float4 a = reinterpret_cast<const float4*>(src1 + er * RN_D)[q];
             if (j >= 0) {
                 const float4 g = reinterpret_cast<const float4*>(src2 + er * RN_D)[q];
-                a.x += gelu_f(g.x); a.y += gelu_f(g.y); a.z += gelu_f(g.z); a.w += gelu_f(g.w);
+                const unsigned long long i0 = (unsigned long long)er * RN_D + 4 * q;
+                a.x += gelu_f(g.x) * drop_mul(dr, site, i0); a.y += gelu_f(g.y) * drop_mul(dr, site, i0 + 1);
+                a.z += gelu_f(g.z) * drop_mul(dr, site, i0 + 2); a.w += gelu_f(g.w) * drop_mul(dr, site, i0 + 3);
             }
             *xp = a;
         }
@@ -212,29 +252,34 @@ __global__ void k_edge_elem(PackInfo pk, int k, const int* __restrict__ nbr, int
 }
 static unsigned edge_grid(const PackInfo& pk, int k) { size_t g = ((size_t)pk.Nmax * k * 32 + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
 void t_edge_add_pq(const PackInfo& pk, int k, const int* nbr, const float* pq, float* pre, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 0, pq, pre, nullptr, nullptr);
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 0, pq, pre, nullptr, nullptr, TDrop{0, 0, 1.f}, 0u);
 }
 void t_edge_zero_invalid(const PackInfo& pk, int k, const int* nbr, float* x, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, x, nullptr, nullptr);
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, x, nullptr, nullptr, TDrop{0, 0, 1.f}, 0u);
 }
-void t_edge_residual(const PackInfo& pk, int k, const int* nbr, const float* e_in, const float* pre2, float* e_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 2, nullptr, e_out, e_in, pre2);
+void t_edge_residual(const PackInfo& pk, int k, const int* nbr, const float* e_in, const float* pre2, float* e_out,
+                     const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_elem, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 2, nullptr, e_out, e_in, pre2, dr, site);
 }
 
 // forward: out[p] = h[p] + sum_valid gelu(pre2[e]) / max(cnt,1);   backward: dpre2[e] = valid ? dagg[p]/cnt * gelu'(pre2[e]) : 0
 __global__ void __launch_bounds__(128) k_seg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ pre2,
-                                                  const float* __restrict__ h, float* __restrict__ out) {
+                                                  const float* __restrict__ h, float* __restrict__ out, TDrop dr, unsigned site) {
     const int p = blockIdx.x;
     if (p >= pk.cu[pk.B]) return;
     const int c = threadIdx.x;
     float s = 0.f; int cnt = 0;
     for (int sl = 0; sl < k; ++sl) {
-        if (nbr[(size_t)p * k + sl] >= 0) { s += gelu_f(pre2[((size_t)p * k + sl) * RN_D + c]); ++cnt; }
+        if (nbr[(size_t)p * k + sl] >= 0) {
+            const size_t o = ((size_t)p * k + sl) * RN_D + c;
+            s += gelu_f(pre2[o]) * drop_mul(dr, site, o);
+            ++cnt;
+        }
     }
     out[(size_t)p * RN_D + c] = h[(size_t)p * RN_D + c] + s / (float)(cnt > 0 ? cnt : 1);
 }
 __global__ void __launch_bounds__(128) k_seg_mean_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ dagg,
-                                                      const float* __restrict__ pre2, float* __restrict__ dpre2) {
+                                                      const float* __restrict__ pre2, float* __restrict__ dpre2, TDrop dr, unsigned site) {
     const int p = blockIdx.x;
     if (p >= pk.cu[pk.B]) return;
     const int c = threadIdx.x;
@@ -243,45 +288,93 @@ __global__ void __launch_bounds__(128) k_seg_mean_bwd(PackInfo pk, int k, const 
     const float g = dagg[(size_t)p * RN_D + c] / (float)(cnt > 0 ? cnt : 1);
     for (int sl = 0; sl < k; ++sl) {
         const size_t o = ((size_t)p * k + sl) * RN_D + c;
-        dpre2[o] = nbr[(size_t)p * k + sl] >= 0 ? g * gelu_d(pre2[o]) : 0.f;
+        dpre2[o] = nbr[(size_t)p * k + sl] >= 0 ? g * gelu_d(pre2[o]) * drop_mul(dr, site, o) : 0.f;
     }
 }
-void t_seg_mean(const PackInfo& pk, int k, const int* nbr, const float* pre2, const float* h, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_seg_mean, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, pre2, h, out);
+void t_seg_mean(const PackInfo& pk, int k, const int* nbr, const float* pre2, const float* h, float* out,
+                const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_seg_mean, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, pre2, h, out, dr, site);
 }
-void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const float* pre2, float* dpre2, hipStream_t s) {
-    hipLaunchKernelGGL(k_seg_mean_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, dagg, pre2, dpre2);
+void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const float* pre2, float* dpre2,
+                    const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_seg_mean_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, dagg, pre2, dpre2, dr, site);
 }
 // dpre2e[e] = valid ? de[e] * gelu'(pre2e[e]) : 0   (edge-update residual branch)
 __global__ void k_edge_res_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ de, const float* __restrict__ pre2,
-                               float* __restrict__ dpre2) {
+                               float* __restrict__ dpre2, TDrop dr, unsigned site) {
     const size_t n = (size_t)pk.cu[pk.B] * k * RN_D;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x)
-        dpre2[id] = nbr[id >> 7] >= 0 ? de[id] * gelu_d(pre2[id]) : 0.f;
+        dpre2[id] = nbr[id >> 7] >= 0 ? de[id] * gelu_d(pre2[id]) * drop_mul(dr, site, id) : 0.f;
 }
-void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_res_bwd, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, de, pre2, dpre2);
+void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2,
+                    const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_res_bwd, dim3(edge_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, de, pre2, dpre2, dr, site);
 }
-// dpq[i][0:128] = sum_slots dpre1 (P part, plain store); dpq[j][128:256] += dpre1 (Q part, atomics; phantom row Nmax absorbs)
-__global__ void __launch_bounds__(128) k_edge_pq_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ dpre1,
-                                                     float* __restrict__ dpq) {
+// Reverse adjacency of the k-NN graph (built once per training forward): for every packed row j the edge rows
+// (p*k + slot) whose neighbour is j, ascending - the gather form of the backward's only true scatter (d Q[j] += ...).
+// Counting uses integer atomics (exact), the fill order is then made canonical by a per-row sort.
+__global__ void k_rev_count(PackInfo pk, int k, const int* __restrict__ nbr, int* __restrict__ deg) {
+    const size_t E = (size_t)pk.cu[pk.B] * k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = nbr[e];
+        if (j >= 0 && j < pk.Nmax) atomicAdd(deg + j, 1);              // phantom neighbours (>= Nmax) carry no gradient
+    }
+}
+__global__ void __launch_bounds__(1024) k_rev_scan(const int* __restrict__ deg, int n, int* __restrict__ start, int* __restrict__ fill) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (n + 1023) / 1024;
+    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += deg[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { int v = part[i]; part[i] = run; run += v; } start[n] = run; }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) { start[i] = run; fill[i] = run; run += deg[i]; }
+}
+__global__ void k_rev_fill(PackInfo pk, int k, const int* __restrict__ nbr, int* __restrict__ fill, int* __restrict__ list) {
+    const size_t E = (size_t)pk.cu[pk.B] * k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = nbr[e];
+        if (j >= 0 && j < pk.Nmax) list[atomicAdd(fill + j, 1)] = (int)e;
+    }
+}
+__global__ void k_rev_sort(PackInfo pk, const int* __restrict__ start, int* __restrict__ list) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= pk.cu[pk.B]) return;
+    const int a = start[j], b = start[j + 1];
+    for (int i = a + 1; i < b; ++i) {                                   // insertion sort: in-degrees are small (~k)
+        const int v = list[i];
+        int t = i - 1;
+        while (t >= a && list[t] > v) { list[t + 1] = list[t]; --t; }
+        list[t + 1] = v;
+    }
+}
+void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, hipStream_t s) {
+    (void)hipMemsetAsync(deg, 0, (size_t)pk.Nmax * sizeof(int), s);
+    size_t E = (size_t)pk.Nmax * k;
+    unsigned g = (unsigned)((E + 255) / 256); if (g > 8192) g = 8192; if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_rev_count, dim3(g), dim3(256), 0, s, pk, k, nbr, deg);
+    hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, s, deg, pk.Nmax, start, fill);
+    hipLaunchKernelGGL(k_rev_fill, dim3(g), dim3(256), 0, s, pk, k, nbr, fill, list);
+    hipLaunchKernelGGL(k_rev_sort, dim3((pk.Nmax + 255) / 256), dim3(256), 0, s, pk, start, list);
+}
+// dpq[i][0:128] = sum_slots dpre1[(i, slot)]  (P part);  dpq[j][128:256] = sum over incoming edges of j, ascending (Q part)
+__global__ void __launch_bounds__(128) k_edge_pq_bwd(PackInfo pk, int k, const float* __restrict__ dpre1,
+                                                     const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ dpq) {
     const int p = blockIdx.x;
     if (p >= pk.cu[pk.B]) return;
     const int c = threadIdx.x;
     float s = 0.f;
-    for (int sl = 0; sl < k; ++sl) {
-        const float v = dpre1[((size_t)p * k + sl) * RN_D + c];
-        s += v;
-        int j = nbr[(size_t)p * k + sl];
-        if (j >= 0) {
-            if (j > pk.Nmax) j = pk.Nmax;
-            atomicAdd(dpq + (size_t)j * 256 + 128 + c, v);
-        }
-    }
+    for (int sl = 0; sl < k; ++sl) s += dpre1[((size_t)p * k + sl) * RN_D + c];
     dpq[(size_t)p * 256 + c] = s;
+    float q = 0.f;
+    for (int t = start[p]; t < start[p + 1]; ++t) q += dpre1[(size_t)list[t] * RN_D + c];
+    dpq[(size_t)p * 256 + 128 + c] = q;
 }
-void t_edge_pq_bwd(const PackInfo& pk, int k, const int* nbr, const float* dpre1, float* dpq, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_pq_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, nbr, dpre1, dpq);
+void t_edge_pq_bwd(const PackInfo& pk, int k, const float* dpre1, const int* start, const int* list, float* dpq, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_pq_bwd, dim3(pk.Nmax), dim3(128), 0, s, pk, k, dpre1, start, list, dpq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -290,11 +383,11 @@ void t_edge_pq_bwd(const PackInfo& pk, int k, const int* nbr, const float* dpre1
 //   dx_i = g_i/sd + dL/dvar * 2 (x_i - mu)/n + dL/dmu / n,   g = dy * scale
 //   dL/dvar = -0.5 sd^-3 sum g_i (x_i - mu),   dL/dmu = -sum g_i / sd + dL/dvar * 2 c mu / n
 __global__ void __launch_bounds__(256) k_gn_bwd(PackInfo pk, const float* __restrict__ x, const float* __restrict__ dy,
-        const float* __restrict__ scale, int t_tot, float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift) {
+        const float* __restrict__ scale, int t_tot, float* __restrict__ dx, float* __restrict__ part) {
     __shared__ float red[4][256];
     const int b = blockIdx.x;
     const int n = pk.len[b];
-    if (n <= 0) return;
+    if (n <= 0) { part[(size_t)b * 256 + threadIdx.x] = 0.f; return; }      // [b][dscale 128 | dshift 128]
     const size_t base = (size_t)pk.cu[b] * RN_D;
     const int c = threadIdx.x & 127, hf = threadIdx.x >> 7;
     const float* xb = x + base;
@@ -323,33 +416,88 @@ __global__ void __launch_bounds__(256) k_gn_bwd(PackInfo pk, const float* __rest
         db[(size_t)r * RN_D + c] = gb[(size_t)r * RN_D + c] * sc / sd + dvar * 2.f * d / fn + dmu / fn;
     }
     if (hf == 0) {
-        if (dshift) atomicAdd(dshift + c, red[2][c] + red[2][c + 128]);
-        if (dscale) atomicAdd(dscale + c, (red[3][c] + red[3][c + 128]) / sd);
+        part[(size_t)b * 256 + c] = (red[3][c] + red[3][c + 128]) / sd;
+        part[(size_t)b * 256 + 128 + c] = red[2][c] + red[2][c + 128];
     }
 }
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
-              float* dshift, hipStream_t s) {
-    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, dscale, dshift);
+              float* dshift, const TScratch& sc, hipStream_t s) {
+    // per-RNA partials of (dscale, dshift), added in RNA order (needs B * 256 floats of scratch)
+    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, sc.p);
+    if (dscale) reduce_parts(sc.p, pk.B, 256, 128, 128, dscale, 128, s);
+    if (dshift) reduce_parts(sc.p + 128, pk.B, 256, 128, 128, dshift, 128, s);
 }
 
 // ------------------------------------------------------------------------------------------
-// attention backward over the valid keys of one RNA (head dim HD), qkv rows [q | k | v], f32.
-// pass 1 (thread per query): row max m, normaliser l, delta = sum_j P_ij (dO_i . v_j), dq_i
-// pass 2 (thread per key):   dv_j = sum_i P_ij dO_i,  dk_j = scale * sum_i dS_ij q_i
+// Training attention over the valid keys of one RNA (head dim HD), qkv rows [q | k | v], f32, with dropout on the
+// attention PROBABILITIES (nn.MultiheadAttention(dropout=p), functional.py:109): O_i = sum_j P_ij M_ij v_j, the softmax
+// normaliser is the unmasked sum.  Mask element index = ((query row * heads + head) << 13) + key (keys < 8192).
+__device__ __forceinline__ unsigned long long att_idx(int qrow, int heads, int hd, int j) {
+    return (((unsigned long long)qrow * heads + hd) << 13) + (unsigned)j;
+}
 template <int HD>
-__global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
-        float* __restrict__ dqkv, float* __restrict__ stat, int heads) {
+__global__ void __launch_bounds__(64) k_attn_fwd_t(PackInfo pk, const float* __restrict__ qkv, int heads, float* __restrict__ out,
+                                                   TDrop dr, unsigned site) {
     const int b = blockIdx.x, hd = blockIdx.y;
     const int n = pk.len[b];
     const int qi = blockIdx.z * 64 + threadIdx.x;
     if (blockIdx.z * 64 >= n) return;
     const int base = pk.cu[b];
     const bool act = qi < n;
+    const int qrow = base + (act ? qi : 0);
     const float scale = rsqrtf((float)HD);
-    const float* row = qkv + (size_t)(base + (act ? qi : 0)) * 384 + hd * HD;
+    const float* qp = qkv + (size_t)qrow * 384 + hd * HD;
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qp[d] * scale; acc[d] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
+        const float* vj = kj + 128;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kj[d], sc);
+        const float mn = fmaxf(m, sc);
+        const float corr = __expf(m - mn), pj = __expf(sc - mn);
+        l = l * corr + pj;
+        const float pm = pj * drop_mul(dr, site, att_idx(qrow, heads, hd, j));
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = fmaf(pm, vj[d], acc[d] * corr);
+        m = mn;
+    }
+    if (act) {
+        const float inv = 1.0f / l;
+        float* op = out + (size_t)qrow * RN_D + hd * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+    }
+}
+int t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, const TDrop& dr, unsigned site, hipStream_t s) {
+    dim3 grid(pk.B, heads, (pk.T + 63) / 64);
+    const int hd = RN_D / heads;
+#define RN_ATT(H) if (hd == H) { hipLaunchKernelGGL(k_attn_fwd_t<H>, grid, dim3(64), 0, s, pk, qkv, heads, out, dr, site); return 0; }
+    RN_ATT(16) RN_ATT(32) RN_ATT(8) RN_ATT(64)
+#undef RN_ATT
+    return 1;
+}
+
+// backward.  pass 1 (thread per query): row max m, normaliser l, delta = sum_j P_ij dP_ij with dP_ij = M_ij (dO_i . v_j), dq_i
+//            pass 2 (thread per key):   dv_j = sum_i P_ij M_ij dO_i,  dk_j = scale * sum_i dS_ij q_i,  dS = P (dP - delta)
+template <int HD>
+__global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
+        float* __restrict__ dqkv, float* __restrict__ stat, int heads, TDrop dr, unsigned site) {
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int qi = blockIdx.z * 64 + threadIdx.x;
+    if (blockIdx.z * 64 >= n) return;
+    const int base = pk.cu[b];
+    const bool act = qi < n;
+    const int qrow = base + (act ? qi : 0);
+    const float scale = rsqrtf((float)HD);
+    const float* row = qkv + (size_t)qrow * 384 + hd * HD;
     float q[HD], g[HD], dq[HD];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { q[d] = row[d] * scale; g[d] = dO[(size_t)(base + (act ? qi : 0)) * RN_D + hd * HD + d]; dq[d] = 0.f; }
+    for (int d = 0; d < HD; ++d) { q[d] = row[d] * scale; g[d] = dO[(size_t)qrow * RN_D + hd * HD + d]; dq[d] = 0.f; }
     float m = -3.0e38f;
     for (int j = 0; j < n; ++j) {
         const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
@@ -366,7 +514,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __r
 #pragma unroll
         for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
         const float pj = __expf(sc - m);
-        l += pj; delta = fmaf(pj, dp, delta);
+        l += pj; delta = fmaf(pj, dp * drop_mul(dr, site, att_idx(qrow, heads, hd, j)), delta);
     }
     delta /= l;
     for (int j = 0; j < n; ++j) {
@@ -375,7 +523,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __r
         float sc = 0.f, dp = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
-        const float ds = __expf(sc - m) / l * (dp - delta);
+        const float ds = __expf(sc - m) / l * (dp * drop_mul(dr, site, att_idx(qrow, heads, hd, j)) - delta);
 #pragma unroll
         for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, kj[d], dq[d]);
     }
@@ -389,15 +537,16 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __r
 }
 template <int HD>
 __global__ void __launch_bounds__(64) k_attn_bwd_kv(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
-        float* __restrict__ dqkv, const float* __restrict__ stat, int heads) {
+        float* __restrict__ dqkv, const float* __restrict__ stat, int heads, TDrop dr, unsigned site) {
     const int b = blockIdx.x, hd = blockIdx.y;
     const int n = pk.len[b];
     const int kj = blockIdx.z * 64 + threadIdx.x;
     if (blockIdx.z * 64 >= n) return;
     const int base = pk.cu[b];
     const bool act = kj < n;
+    const int kc = act ? kj : 0;
     const float scale = rsqrtf((float)HD);
-    const float* row = qkv + (size_t)(base + (act ? kj : 0)) * 384 + 128 + hd * HD;
+    const float* row = qkv + (size_t)(base + kc) * 384 + 128 + hd * HD;
     float kk[HD], vv[HD], dk[HD], dv[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) { kk[d] = row[d]; vv[d] = row[128 + d]; dk[d] = 0.f; dv[d] = 0.f; }
@@ -408,10 +557,12 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(PackInfo pk, const float* __
         float sc = 0.f, dp = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) { sc = fmaf(qi[d] * scale, kk[d], sc); dp = fmaf(gi[d], vv[d], dp); }
+        const float mk = drop_mul(dr, site, att_idx(base + i, heads, hd, kc));
         const float pij = __expf(sc - st[0]) / st[1];
-        const float ds = pij * (dp - st[2]);
+        const float ds = pij * (dp * mk - st[2]);
+        const float pm = pij * mk;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pij, gi[d], dv[d]); dk[d] = fmaf(ds, qi[d] * scale, dk[d]); }
+        for (int d = 0; d < HD; ++d) { dv[d] = fmaf(pm, gi[d], dv[d]); dk[d] = fmaf(ds, qi[d] * scale, dk[d]); }
     }
     if (act) {
         float* o = dqkv + (size_t)(base + kj) * 384 + 128 + hd * HD;
@@ -419,21 +570,24 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(PackInfo pk, const float* __
         for (int d = 0; d < HD; ++d) { o[d] = dk[d]; o[128 + d] = dv[d]; }
     }
 }
-int t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat, hipStream_t s) {
+int t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat,
+                    const TDrop& dr, unsigned site, hipStream_t s) {
     dim3 grid(pk.B, heads, (pk.T + 63) / 64);
     const int hd = RN_D / heads;
 #define RN_ATT(H) \
-    if (hd == H) { hipLaunchKernelGGL(k_attn_bwd_q<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads); \
-                   hipLaunchKernelGGL(k_attn_bwd_kv<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads); return 0; }
+    if (hd == H) { hipLaunchKernelGGL(k_attn_bwd_q<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads, dr, site); \
+                   hipLaunchKernelGGL(k_attn_bwd_kv<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads, dr, site); return 0; }
     RN_ATT(16) RN_ATT(32) RN_ATT(8) RN_ATT(64)
 #undef RN_ATT
     return 1;
 }
 
 // ------------------------------------------------------------------------------------------
-// loss = mean_valid CE(softmax(logits), label)  (softmax applied twice, rnampnn.py:151-154,201-204)
+// loss = mean_valid CE(softmax(logits), label)  (softmax applied twice, rnampnn.py:151-154,201-204) and its gradient with
+// respect to the logits.  Per-workgroup partial losses, summed in block order by a one-thread second stage.
 __global__ void __launch_bounds__(256) k_loss_grad(PackInfo pk, const float* __restrict__ logits, const int32_t* __restrict__ labels,
-                                                   float* __restrict__ dlogits, float* __restrict__ loss) {
+                                                   float* __restrict__ dlogits, float* __restrict__ part) {
+    __shared__ float red[4];
     const int ntot = pk.cu[pk.B];
     float local = 0.f;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < ntot; p += gridDim.x * blockDim.x) {
@@ -456,10 +610,33 @@ __global__ void __launch_bounds__(256) k_loss_grad(PackInfo pk, const float* __r
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
-    if ((threadIdx.x & 63) == 0 && ntot > 0) atomicAdd(loss, local / (float)ntot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(ntot > 0 ? ntot : 1);
 }
-void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, hipStream_t s) {
+__global__ void k_loss_sum(const float* __restrict__ part, int n, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    *loss = s;
+}
+void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, const TScratch& sc,
+                 hipStream_t s) {
     int grid = (pk.Nmax + 255) / 256;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_loss_grad, dim3(grid), dim3(256), 0, s, pk, logits, labels, dlogits, loss);
+    hipLaunchKernelGGL(k_loss_grad, dim3(grid), dim3(256), 0, s, pk, logits, labels, dlogits, sc.p);
+    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(1), 0, s, sc.p, grid, loss);
+}
+
+// d loss / d logits handed in by the caller (autograd) in the padded (B,T,4) layout -> packed rows
+__global__ void k_unpack_dlogits(PackInfo pk, const float* __restrict__ src, float* __restrict__ dst) {
+    const int ntot = pk.cu[pk.B];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < ntot; p += gridDim.x * blockDim.x) {
+        const int b = pk.node_b[p];
+        reinterpret_cast<float4*>(dst)[p] = reinterpret_cast<const float4*>(src)[(size_t)b * pk.T + (p - pk.cu[b])];
+    }
+}
+void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlogits_p, hipStream_t s) {
+    int grid = (pk.Nmax + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_unpack_dlogits, dim3(grid), dim3(256), 0, s, pk, dlogits_padded, dlogits_p);
 }

@@ -18,6 +18,31 @@
 
 typedef unsigned short bf16_t;   // raw bf16 bits
 
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once PER DEVICE (the attribute lives with the
+// device's code object): remembered per device id, thread-safe, grows monotonically.
+#include <mutex>
+struct DevAttr { std::mutex mu; size_t have[64] = {}; };
+static inline void ensure_dyn_lds(const void* fn, size_t bytes, DevAttr& st) {
+    if (bytes <= 64 * 1024) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(st.mu);
+    size_t& h = st.have[dev & 63];
+    if (h < bytes) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); h = bytes; }
+}
+// CU count of the CURRENT device (cached per device id)
+static inline int rn_num_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& n = cus[dev & 63];
+    if (!n) {
+        hipDeviceProp_t p;
+        n = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 struct PackInfo {            // device arrays describing the packed batch
     int* len;                // [B]    valid length n_b
     int* cu;                 // [B+1]  exclusive prefix sum; cu[B] = N_tot

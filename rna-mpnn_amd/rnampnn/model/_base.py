@@ -100,10 +100,6 @@ class NativeModule(nn.Module):
 
     def _ensure(self) -> torch.device:
         device = self._device()
-        if self.training and not self._warned_train:
-            self._warned_train = True
-            import warnings
-            warnings.warn("rnampnn HIP forward implements eval-mode semantics (dropout inactive)")
         if self._handle is None:
             self._handle = _native.Handle(self._hp, _PREC[self.precision])
         named = dict(self.named_parameters())
@@ -124,14 +120,22 @@ class NativeModule(nn.Module):
         return device
 
     def _workspace(self, B: int, T: int, device) -> torch.Tensor:
+        """The module's shared scratch (grown on demand).  A hipGraph must never bake pointers into it - a later, larger
+        call would free the buffer under the graph - so captures bring their own (``_ws_args(..., private=...)``)."""
         need = int(_native.lib().rnampnn_workspace_bytes(self._handle.ptr, B, T))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+        if self._ws is None or self._ws.numel() < need + 256 or self._ws.device != device:
             self._ws = None
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
         return self._ws
 
-    def _ws_args(self, B: int, T: int, device):
-        ws = self._workspace(B, T, device)
+    def new_workspace(self, B: int, T: int) -> torch.Tensor:
+        """A private workspace tensor for (B, T), owned by the caller (hipGraph captures)."""
+        device = self._ensure()
+        need = int(_native.lib().rnampnn_workspace_bytes(self._handle.ptr, B, T))
+        return torch.empty(need + 256, dtype=torch.uint8, device=device)
+
+    def _ws_args(self, B: int, T: int, device, private: Optional[torch.Tensor] = None):
+        ws = private if private is not None else self._workspace(B, T, device)
         base = ws.data_ptr()
         aligned = (base + 255) // 256 * 256
         return C.c_void_p(aligned), C.c_size_t(ws.numel() - (aligned - base))

@@ -10,6 +10,7 @@ and checkpoint hooks.  New (no reference counterpart): ``samp
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -18,8 +19,11 @@ import torch.nn.functional as F
 
 from .. import _native
 from ..config.glob import REVERSE_VOCAB
+from ..utils.data import check_prefix_mask
 from ._base import NativeModule, _prep, _ptr, _stream
 from ._schema import DEFAULT_HPARAMS
+
+_CHECK_MASKS = os.environ.get("RNAMPNN_CHECK_MASKS", "0") == "1"
 
 _FIXED_ATOMS = dict(num_inside_dist_atoms=7, num_inside_angle_atoms=6, num_inside_dihedral_atoms=6,
                     num_cross_dist_atoms=7, num_cross_angle_atoms=6, num_cross_dihedral_atoms=6)
@@ -42,13 +46,16 @@ class RNAMPNN(NativeModule):
         self.val_step_outputs = {'val_loss': [], 'correct': [], 'len': [], 'recovery_rates': []}
 
     # ------------------------------------------------------------------ forward surface
-    def _run(self, coords, mask, want_logits=True, want_embedding=False, T_norm: int = 0, taps: Optional[Dict] = None):
+    def _run(self, coords, mask, want_logits=True, want_embedding=False, T_norm: int = 0, taps: Optional[Dict] = None,
+             workspace: Optional[torch.Tensor] = None):
         device = self._ensure()
         if coords.dim() != 4 or coords.shape[2:] != (7, 3):
             raise ValueError(f"coords must be (B, T, 7, 3), got {tuple(coords.shape)}")
         B, T = int(coords.shape[0]), int(coords.shape[1])
         if tuple(mask.shape) != (B, T):
             raise ValueError(f"mask must be (B, T) = {(B, T)}, got {tuple(mask.shape)}")
+        if _CHECK_MASKS:            # opt-in (host sync): the kernels take sum(mask) as the length of a PREFIX mask
+            check_prefix_mask(mask)
         c = _prep(coords, device)
         m = _prep(mask, device)
         k = self._hp["num_res_neighbours"]
@@ -73,7 +80,7 @@ class RNAMPNN(NativeModule):
             io.tap_layer = int(taps.get("tap_layer", 0))
             io.stop_after = int(taps.get("stop_after", 0))
         with torch.cuda.device(device):
-            ws, ws_bytes = self._ws_args(B, T, device)
+            ws, ws_bytes = self._ws_args(B, T, device, workspace)
             _native.check(_native.lib().rnampnn_forward(self._handle.ptr, C.byref(io), ws, ws_bytes, _stream(device)))
         return out
 
@@ -81,7 +88,61 @@ class RNAMPNN(NativeModule):
         """``RNAMPNN.forward`` (rnampnn.py:161-185): logits (B, T, 4), zero on padded rows.
         ``T_norm`` (extension): node-axis length GraphNormalization should see when this call holds
         only a shard of a padded global batch (0 = this tensor's T)."""
+        if self.training:       # train mode = the reference's nn.Dropout / MHA dropout active (rnampnn.py:47,109-134)
+            return self._forward_train(coords, mask, T_norm)
         return self._run(coords, mask, T_norm=T_norm)["logits"]
+
+    # ------------------------------------------------------------------ training forward (autograd-visible)
+    def manual_seed(self, seed: int) -> None:
+        """Base seed of the dropout masks; call ``t`` of ``forward`` in train mode uses (seed << 32) + t."""
+        self._drop_base, self._drop_calls = int(seed) & 0x7FFFFFFF, 0
+
+    def _next_seed(self) -> int:
+        self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+        return (getattr(self, "_drop_base", 0) << 32) + self._drop_calls
+
+    def _train_ws(self, B: int, T: int, device):
+        need = int(_native.lib().rnampnn_train_workspace_bytes(self._handle.ptr, B, T))
+        if getattr(self, "_tws", None) is None or self._tws.numel() < need + 256 or self._tws.device != device:
+            self._tws = None
+            self._tws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        base = self._tws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        return C.c_void_p(aligned), C.c_size_t(self._tws.numel() - (aligned - base))
+
+    def _train_forward_native(self, coords, mask, T_norm: int, dropout: float, seed: int) -> torch.Tensor:
+        device = self._ensure()
+        B, T = int(coords.shape[0]), int(coords.shape[1])
+        c, m = _prep(coords, device), _prep(mask, device)
+        logits = torch.empty(B, T, 4, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            ws, ws_bytes = self._train_ws(B, T, device)
+            _native.check(_native.lib().rnampnn_train_forward(self._handle.ptr, _ptr(c), _ptr(m), B, T, int(T_norm), float(dropout),
+                                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(logits), ws, ws_bytes,
+                                                              _stream(device)))
+        return logits
+
+    def _train_backward_native(self, dlogits: torch.Tensor) -> None:
+        device = self._device()
+        B, T = int(dlogits.shape[0]), int(dlogits.shape[1])
+        fresh = self._bind_flat_grad(device)
+        d = _prep(dlogits, device)
+        with torch.cuda.device(device):
+            ws, ws_bytes = self._train_ws(B, T, device)
+            _native.check(_native.lib().rnampnn_train_backward(self._handle.ptr, _ptr(d), B, T, 0 if fresh else 1,
+                                                               _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
+
+    def _forward_train(self, coords, mask, T_norm: int = 0, dropout: Optional[float] = None, seed: Optional[int] = None):
+        """The reference's ``self(coords, mask)`` inside ``training_step`` (rnampnn.py:199): logits carrying an autograd
+        node, so ``loss.backward()`` (Lightning's automatic optimisation) reaches every parameter.  Runs the taped f32
+        kernels; the parameter gradients are written into ``flat_grad`` (``p.grad`` are views of it) by the HIP backward."""
+        if coords.dim() != 4 or coords.shape[2:] != (7, 3) or tuple(mask.shape) != tuple(coords.shape[:2]):
+            raise ValueError(f"coords must be (B, T, 7, 3) and mask (B, T), got {tuple(coords.shape)} / {tuple(mask.shape)}")
+        p = float(self._hp["dropout"] if dropout is None else dropout)
+        sd = self._next_seed() if seed is None else int(seed)
+        if not torch.is_grad_enabled():
+            return self._train_forward_native(coords, mask, T_norm, p, sd)
+        return _TrainForward.apply(self, coords, mask, int(T_norm), p, sd, *self.parameters())
 
     def embedding(self, coords: torch.Tensor, mask: torch.Tensor, is_predict: bool = False, T_norm: int = 0) -> torch.Tensor:
         """``RNAMPNN.embedding`` (rnampnn.py:269-278): cat(post-fusion h, raw embedding), (B, T, 256)."""
@@ -95,6 +156,15 @@ class RNAMPNN(NativeModule):
         RNA.  Returns packed logits (N,4) [and embedding (N,256)] - identical, row for row, to the valid rows
         of ``forward`` on the same batch padded to ``max_len`` - without moving or touching any padding."""
         device = self._ensure()
+        if coords_packed.dim() != 3 or coords_packed.shape[1:] != (7, 3):
+            raise ValueError(f"coords_packed must be (N, 7, 3), got {tuple(coords_packed.shape)}")
+        if cu_seqlens.device.type == "cpu" or _CHECK_MASKS:      # free on the host (pack_batch's output); opt-in sync otherwise
+            cu_h = cu_seqlens.detach().cpu().to(torch.int64)
+            d = cu_h[1:] - cu_h[:-1]
+            if cu_h.numel() < 2 or int(cu_h[0]) != 0 or bool((d < 0).any()) or int(cu_h[-1]) != int(coords_packed.shape[0]):
+                raise ValueError("cu_seqlens must be a non-decreasing prefix sum from 0 to N = coords_packed.shape[0]")
+            if int(d.max()) > int(max_len):
+                raise ValueError(f"an RNA of {int(d.max())} nt exceeds max_len = {int(max_len)}")
         c = _prep(coords_packed, device)
         cu = _prep(cu_seqlens, device, torch.int32)
         B, N = int(cu.numel()) - 1, int(c.shape[0])
@@ -140,45 +210,66 @@ class RNAMPNN(NativeModule):
 
     # ------------------------------------------------------------------ training / validation surface
     def loss_and_grad(self, sequences: torch.Tensor, coords: torch.Tensor, mask: torch.Tensor, T_norm: int = 0,
-                      return_logits: bool = False):
+                      return_logits: bool = False, dropout: Optional[float] = None, seed: Optional[int] = None):
         """``training_step`` + ``loss.backward()`` of the reference (rnampnn.py:187-207) in one native call:
         forward, loss = cross_entropy(softmax(logits)[valid], label) and the gradient of every parameter
-        (f32 HIP kernels; dropout is not applied).  ``sequences`` is the collate's one-hot (B,T,4) or class
-        ids (B,T).  Afterwards every ``p.grad`` is a view into ONE flat buffer (``self.flat_grad``), so a
-        data-parallel job all-reduces gradients with a single RCCL call (``allreduce_gradients``)."""
+        (f32 HIP kernels, bit-reproducible).  ``dropout``: None = the module's hyper-parameter in train mode and 0 in eval
+        mode; masks are a function of ``seed`` (None = the module's running counter, ``manual_seed``).  ``sequences`` is the
+        collate's one-hot (B,T,4) or class ids (B,T).  Afterwards every ``p.grad`` is a view into ONE flat buffer
+        (``self.flat_grad``, overwritten), so a data-parallel job all-reduces gradients with a single RCCL call
+        (``allreduce_gradients``)."""
         device = self._ensure()
         B, T = int(coords.shape[0]), int(coords.shape[1])
         c, m = _prep(coords, device), _prep(mask, device)
         lab = sequences.argmax(dim=-1) if sequences.dim() == 3 else sequences
         lab = _prep(lab, device, torch.int32)
         lib = _native.lib()
+        self._bind_flat_grad(device)
+        loss = torch.zeros((), dtype=torch.float32, device=device)
+        logits = torch.empty(B, T, 4, dtype=torch.float32, device=device) if return_logits else None
+        p = float((self._hp["dropout"] if self.training else 0.0) if dropout is None else dropout)
+        sd = self._next_seed() if seed is None else int(seed)
+        with torch.cuda.device(device):
+            ws, ws_bytes = self._train_ws(B, T, device)
+            _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm), p,
+                                                    C.c_uint64(sd & (2 ** 64 - 1)), _ptr(loss), _ptr(logits),
+                                                    _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
+        return (loss, logits) if return_logits else loss
+
+    def _bind_flat_grad(self, device) -> bool:
+        """(Re-)bind every ``p.grad`` to its slice of ONE flat buffer laid out like the weight arena.  Checked on every call:
+        ``optimizer.zero_grad()`` (set_to_none=True, torch's and Lightning's default) drops the views, and a parameter
+        whose ``.grad`` no longer aliases the buffer would silently stop being updated.  Returns True when any view had
+        to be (re)made, i.e. the gradients were reset since the last backward (the next backward overwrites)."""
+        lib = _native.lib()
         if getattr(self, "flat_grad", None) is None or self.flat_grad.device != device:
-            n = int(lib.rnampnn_grad_numel(self._handle.ptr))
-            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+            self.flat_grad = torch.zeros(int(lib.rnampnn_grad_numel(self._handle.ptr)), dtype=torch.float32, device=device)
+            self._grad_slices = None
+        if getattr(self, "_grad_slices", None) is None:
             named = dict(self.named_parameters())
+            self._grad_slices = []
             for i, (key, _) in enumerate(self._handle.weight_schema()):
                 off = C.c_int64()
                 _native.check(lib.rnampnn_weight_offset(self._handle.ptr, i, C.byref(off)))
-                p = named[key]
-                p.grad = self.flat_grad[off.value: off.value + p.numel()].view(p.shape)
-        loss = torch.zeros((), dtype=torch.float32, device=device)
-        logits = torch.empty(B, T, 4, dtype=torch.float32, device=device) if return_logits else None
-        need = int(lib.rnampnn_train_workspace_bytes(self._handle.ptr, B, T))
-        if getattr(self, "_tws", None) is None or self._tws.numel() < need + 256 or self._tws.device != device:
-            self._tws = None
-            self._tws = torch.empty(need + 256, dtype=torch.uint8, device=device)
-        base = self._tws.data_ptr()
-        aligned = (base + 255) // 256 * 256
-        with torch.cuda.device(device):
-            _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm),
-                                                    _ptr(loss), _ptr(logits), _ptr(self.flat_grad), C.c_void_p(aligned),
-                                                    C.c_size_t(self._tws.numel() - (aligned - base)), _stream(device)))
-        return (loss, logits) if return_logits else loss
+                self._grad_slices.append((named[key], int(off.value)))
+        base = self.flat_grad.data_ptr()
+        fresh = False
+        for p, off in self._grad_slices:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grad[off: off + p.numel()].view(p.shape)
+                fresh = True
+        return fresh
 
     def training_step(self, batch):
-        """rnampnn.py:187-207.  Returns the loss; gradients are already in ``p.grad`` (no autograd graph)."""
+        """rnampnn.py:187-207, line for line: forward -> softmax -> boolean-mask select -> mix_loss.  The returned loss
+        carries an autograd graph: ``loss.backward()`` runs the HIP backward and fills ``p.grad``."""
         sequences, coords, mask, _ = batch
-        return self.loss_and_grad(sequences, coords, mask)
+        device = self._device()
+        sequences, mask = sequences.to(device), mask.to(device)
+        logits = self(coords, mask)
+        probs = F.softmax(logits, dim=-1)
+        valid = mask.bool()
+        return self.mix_loss(probs[valid], sequences[valid])
 
     def allreduce_gradients(self) -> None:
         """Average ``flat_grad`` over the ranks of the default process group (RCCL on the GPUs): the one
@@ -218,6 +309,23 @@ class RNAMPNN(NativeModule):
         self.val_step_outputs['len'].append(n_tot)
         self.val_step_outputs['recovery_rates'] += recovery_rates
         return {'validation loss': loss, 'recovery_rates': recovery_rates}
+
+
+class _TrainForward(torch.autograd.Function):
+    """Autograd node of the taped HIP forward.  The parameters are inputs only so that autograd schedules ``backward``;
+    their gradients are written by the HIP backward straight into the module's flat buffer (``p.grad`` are views of it,
+    accumulated across backward calls until the gradients are reset, as torch does), so ``None`` is returned for them."""
+
+    @staticmethod
+    def forward(ctx, model, coords, mask, T_norm, dropout, seed, *params):
+        ctx.model = model
+        ctx.n_params = len(params)
+        return model._train_forward_native(coords, mask, T_norm, dropout, seed)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.model._train_backward_native(dlogits)
+        return (None,) * (6 + ctx.n_params)
 
 
 def argmax_recovery(logits: torch.Tensor, mask: torch.Tensor, labels: Optional[torch.Tensor]
@@ -263,6 +371,9 @@ class CapturedSampler:
         self.mask = torch.zeros(B, T, dtype=torch.float32, device=device)
         self.mask[:, 0] = 1
         self.seed = torch.zeros(1, dtype=torch.int64, device=device)
+        # private workspace: the graph bakes raw pointers into it, so it must not be the module's shared scratch (which a later,
+        # larger eager call reallocates) and it lives exactly as long as this object
+        self._ws = model.new_workspace(B, T)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):                       # warm-up: one-time function attributes, workspace growth
@@ -275,7 +386,7 @@ class CapturedSampler:
             self.logits, self.samples = self._step()
 
     def _step(self):
-        logits = self.model.forward(self.coords, self.mask, T_norm=self.T_norm)
+        logits = self.model._run(self.coords, self.mask, T_norm=self.T_norm, workspace=self._ws)["logits"]
         out = torch.empty(self.n_samples, self.B, self.T, dtype=torch.int8, device=logits.device)
         with torch.cuda.device(logits.device):
             _native.check(_native.lib().rnampnn_sample_dev_seed(
@@ -285,7 +396,10 @@ class CapturedSampler:
 
     @torch.no_grad()
     def __call__(self, coords: torch.Tensor, mask: torch.Tensor, seed: int = 0):
-        """-> (logits (B,T,4), samples int8 (n_samples,B,T)) - static tensors, overwritten by the next call."""
+        """-> (logits (B,T,4), samples int8 (n_samples,B,T)) - static tensors, overwritten by the next call.
+        Weights changed since the capture (optimizer step, load_state_dict) are re-uploaded first: the graph reads the
+        library's weight arena, whose address does not change."""
+        self.model._ensure()
         self.coords.copy_(coords, non_blocking=True)
         self.mask.copy_(mask, non_blocking=True)
         self.seed.fill_(int(seed) & (2 ** 63 - 1))

@@ -47,3 +47,151 @@ def pack_batch(coords_list: Sequence[torch.Tensor], pin: bool = True):
     if pin and torch.cuda.is_available():
         cu = cu.pin_memory()
     return packed, cu, int(lengths.max()) if len(coords_list) else 0
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Host input pipeline: dataset directory -> length buckets -> packed pinned batches
+# -> asynchronous host-to-device copies.  Mirrors the ROLE of the reference's RNADataset / RNADataModule
+# (rnampnn/utils/data.py:155-258, 397-539) for the hot path; PDB parsing, plotting and CSV tools are not mirrored.
+import glob as _glob
+import os as _os
+import queue as _queue
+import threading as _threading
+
+import numpy as _np
+
+from ..config.glob import NUM_RES_TYPES, VOCAB
+from . import synth as _synth
+
+
+def fill_nan_deterministic(coords: "_np.ndarray", rna_id: str) -> "_np.ndarray":
+    """Deterministic replacement for the reference's NaN fill (``RNADataset.__fill_nan_with_mean``,
+    rnampnn/utils/data.py:190-222).  Same geometry, atom by atom and in place like the reference: a missing atom
+    a < 6 goes 1.5 A from the first atom of its residue that is present at that moment, a missing atom 6 goes
+    ``NUM_RES_TYPES`` (= 4) A from atom 5; whatever is still NaN becomes 0.  The reference draws the direction from the
+    UNSEEDED global ``np.random`` stream (order- and process-dependent, so no two runs see the same structure); here it
+    is a unit vector from the counter RNG of ``rnampnn.utils.synth`` keyed by (rna id, residue, atom): the same file
+    gives the same coordinates on every box, rank and epoch."""
+    c = _np.array(coords, dtype=_np.float32, copy=True)
+    stream = _synth._fnv1a64("nan_fill/" + rna_id)
+    for a in range(c.shape[1]):
+        missing = _np.where(_np.isnan(c[:, a, :]).any(axis=1))[0]
+        for r in missing:
+            g = _synth.normal01(stream, _np.arange(3, dtype=_np.uint64) + _np.uint64(3 * (r * c.shape[1] + a)))
+            g = g / max(float(_np.linalg.norm(g)), 1e-12)
+            if a < 6:
+                present = _np.where(~_np.isnan(c[r]).any(axis=1))[0]
+                if len(present) > 0:
+                    c[r, a] = c[r, present[0]] + 1.5 * g
+            elif not _np.isnan(c[r, 5]).any():
+                c[r, a] = c[r, 5] + float(NUM_RES_TYPES) * g
+    c[_np.isnan(c)] = 0.0
+    return c
+
+
+def read_fasta(path: str) -> str:
+    return "".join(line.strip() for line in open(path) if not line.startswith(">"))
+
+
+def load_rna_dir(path: str, max_len: int = 1 << 30, nan_policy: str = "skip"):
+    """The reference's data layout (``RNADataset.from_path``, utils/data.py:155-187): ``coords/<id>.npy`` (L,7,3) +
+    ``seqs/<id>.fasta`` -> list of (id, coords f32 (L,7,3), labels int64 (L,)) in id order.  ``nan_policy``: "skip"
+    drops structures with missing atoms, "fill" applies ``fill_nan_deterministic``.  Entries whose sequence length
+    differs from the coordinate count, or with letters outside AUCG, are dropped."""
+    if nan_policy not in ("skip", "fill"):
+        raise ValueError("nan_policy must be 'skip' or 'fill'")
+    items = []
+    for f in sorted(_glob.glob(_os.path.join(path, "coords", "*.npy"))):
+        rid = _os.path.splitext(_os.path.basename(f))[0]
+        fa = _os.path.join(path, "seqs", rid + ".fasta")
+        if not _os.path.exists(fa):
+            continue
+        c = _np.load(f, allow_pickle=False).astype(_np.float32)
+        seq = read_fasta(fa)
+        if c.ndim != 3 or c.shape[1:] != (7, 3) or c.shape[0] != len(seq) or c.shape[0] > max_len or c.shape[0] == 0:
+            continue
+        if any(ch not in VOCAB for ch in seq):
+            continue
+        if _np.isnan(c).any():
+            if nan_policy == "skip":
+                continue
+            c = fill_nan_deterministic(c, rid)
+        items.append((rid, c, _np.array([VOCAB[ch] for ch in seq], dtype=_np.int64)))
+    return items
+
+
+def bucket_batches(lengths: Sequence[int], batch_size: int, max_rows: int = 1 << 30, seed: int = 0) -> List[List[int]]:
+    """Length-bucketed batches: indices sorted by length (ties by index) are cut greedily into batches of at most
+    ``batch_size`` RNAs and at most ``max_rows`` padded rows (B * longest); a single RNA longer than ``max_rows`` gets a
+    batch of its own.  The ORDER of the batches is shuffled by ``seed`` (counter RNG: identical on every rank)."""
+    order = sorted(range(len(lengths)), key=lambda i: (int(lengths[i]), i))
+    batches: List[List[int]] = []
+    cur: List[int] = []
+    for i in order:
+        n = int(lengths[i])            # ascending, so n is the longest of cur + [i]
+        if cur and (len(cur) >= batch_size or (len(cur) + 1) * n > max_rows):
+            batches.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    u = _synth.uniform01(_synth._fnv1a64(f"bucket_order/{seed}"), _np.arange(len(batches), dtype=_np.uint64))
+    return [batches[i] for i in _np.argsort(u, kind="stable")]
+
+
+class PackedLoader:
+    """Asynchronous var-len loader: a background thread collates the next batches with ``pack_batch`` into pinned host
+    memory; ``__iter__`` yields (coords_packed, cu_seqlens, max_len, indices) ALREADY ON THE DEVICE - the host-to-device
+    copy of batch i+1 is issued on a side stream while the kernels of batch i run, and the consumer's stream waits on
+    the copy's event only (no host synchronisation).  ``items`` is a list of coords arrays or of (id, coords, labels)
+    tuples as ``load_rna_dir`` returns; ``batches`` a list of index lists (``bucket_batches``)."""
+
+    def __init__(self, items, batches: Sequence[Sequence[int]], device=None, prefetch: int = 2):
+        self.items, self.batches, self.prefetch = items, [list(b) for b in batches], max(1, int(prefetch))
+        self.device = torch.device(device) if device is not None else None
+
+    def _coords(self, i):
+        it = self.items[i]
+        c = it[1] if isinstance(it, tuple) else it
+        return torch.as_tensor(c, dtype=torch.float32)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        q: "_queue.Queue" = _queue.Queue(maxsize=self.prefetch)
+        use_gpu = self.device is not None and self.device.type == "cuda"
+        side = torch.cuda.Stream(self.device) if use_gpu else None
+
+        def worker():
+            try:
+                for b in self.batches:
+                    packed, cu, max_len = pack_batch([self._coords(i) for i in b], pin=use_gpu)
+                    if use_gpu:
+                        with torch.cuda.stream(side):
+                            dp = packed.to(self.device, non_blocking=True)
+                            dc = cu.to(self.device, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        q.put((dp, dc, max_len, b, ev, (packed, cu)))      # keep the pinned source alive until consumed
+                    else:
+                        q.put((packed, cu, max_len, b, None, None))
+                q.put(None)
+            except BaseException as exc:       # surface loader errors in the consumer
+                q.put(exc)
+
+        th = _threading.Thread(target=worker, daemon=True)
+        th.start()
+        while True:
+            got = q.get()
+            if got is None:
+                break
+            if isinstance(got, BaseException):
+                raise got
+            dp, dc, max_len, b, ev, _keep = got
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                dp.record_stream(torch.cuda.current_stream(self.device))
+                dc.record_stream(torch.cuda.current_stream(self.device))
+            yield dp, dc, max_len, b
+        th.join()

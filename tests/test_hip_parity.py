@@ -3,7 +3,10 @@
 seeded synthetic inputs.
 
 Tolerances: f32 kernels |dlogit| <= 1e-4 and identical argmax except
-near-ties; bf16 kernels |dlogit| <= 5e-2 and recovery within +-0.5 pt of the f32 path.
+near-ties; bf16 kernels: SURVEY's 5e-2 is 70 % of the logit spread at random init (std ~ 0.07), so the bound used here
+is relative to the spread - max(3e-2, 5 % of the std of the reference logits) - and the second half of the criterion
+(argmax agreement / recovery within +-0.5 pt on SEPARATED logits) is asserted on trained weights in
+tests/test_configs_gpu.py::test_trained_weights_bf16_tracks_f32_oracle.
 """
 import numpy as np
 import pytest
@@ -14,7 +17,15 @@ from conftest import FULL_CASES, GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 F32_LOGIT_TOL = 1e-4
-BF16_LOGIT_TOL = 5e-2
+BF16_LOGIT_TOL = 3e-2        # floor of bf16_tol(); random-init logits have std ~ 0.07
+
+
+def bf16_tol(ref, mask=None) -> float:
+    """max(3e-2, 5 % of the standard deviation of the reference logits over valid positions)."""
+    r = torch.as_tensor(ref)
+    if mask is not None:
+        r = r[torch.as_tensor(mask).bool()]
+    return max(BF16_LOGIT_TOL, 0.05 * float(r.std())) if r.numel() > 1 else BF16_LOGIT_TOL
 
 
 def _model(hp, shapes, precision):
@@ -98,7 +109,9 @@ def test_f32_matches_oracle_on_synthetic_batch():
     micro, macro, per = O.recovery(ref, torch.from_numpy(mask), torch.from_numpy(labels))
     assert nvalid.cpu().tolist() == lens
     mine_micro = float(correct.sum()) / float(nvalid.sum())
-    assert abs(mine_micro - micro) < 1e-9 or (logits.cpu() - ref).abs().max() > 0   # ties aside, identical
+    top2 = torch.sort(ref, -1).values
+    unclear = int((((top2[..., -1] - top2[..., -2]) <= 1e-4) & torch.from_numpy(mask).bool()).sum())   # near-ties may flip
+    assert abs(mine_micro - micro) <= unclear / float(sum(lens)) + 1e-9
     assert np.allclose((correct.float() / nvalid.float()).cpu().numpy(), per.numpy(), atol=1e-6)
     loss = O.loss_double_softmax(logits.cpu(), torch.from_numpy(mask), torch.from_numpy(labels))
     ref_loss = O.loss_double_softmax(ref, torch.from_numpy(mask), torch.from_numpy(labels))
@@ -233,7 +246,8 @@ def test_sample_and_argmax_decode():
     assert torch.equal(again, hot[:8])          # counter-based RNG: reproducible
 
 
-@pytest.mark.parametrize("name", ["c1_1b23_k16_P66", "ragged_k30", "c2_mini_k30", "c1_1b23_k30_T80"])
+@pytest.mark.parametrize("name", ["c1_1b23_k16_P66", "ragged_k30", "c2_mini_k30", "c1_1b23_k30_T80", "c1_1b23_k3_default",
+                                  "phantom_n5_T8_k6", "c1_1b23_k16_P4500"])
 def test_bf16_path_within_tolerance(golden, name):
     arrs, hp, shapes = golden(name)
     coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
@@ -244,7 +258,8 @@ def test_bf16_path_within_tolerance(golden, name):
         pytest.skip(f"bf16 kernels unavailable for this configuration: {exc}")
     assert np.isfinite(logits).all()
     err = np.abs(logits - arrs["logits"]).max()
-    assert err < BF16_LOGIT_TOL, f"{name}: |dlogit| = {err:.3e}"
+    assert err < bf16_tol(arrs["logits"], arrs["mask"]), f"{name}: |dlogit| = {err:.3e}"
+    assert (logits[arrs["mask"] == 0] == 0).all()
     labels = arrs["labels"]
     valid = arrs["mask"] > 0
     rec_bf16 = (logits.argmax(-1) == labels)[valid].mean()
@@ -343,6 +358,82 @@ def test_loss_and_gradients_match_oracle_autograd(cfg):
     opt.step()
     assert not torch.equal(before, model.readout.readout_layers._modules["0"].weight.detach())
     print(f"{cfg}: loss {float(loss):.6f}, worst relative gradient error {worst:.2e}")
+
+
+def test_gradients_with_dropout_match_oracle_autograd_and_are_bit_reproducible():
+    """Train-mode semantics: dropout 0.4 at every site of the reference (after every GELU, on the
+    attention probabilities) with the counter-hash masks the oracle restates -> loss, logits and every gradient match
+    oracle autograd with the SAME masks; two calls give bit-identical gradients (ordered reductions, no float atomics);
+    a different seed gives a different loss."""
+    from rnampnn.utils import synth
+    from rnampnn.model._schema import DEFAULT_HPARAMS, state_dict_shapes
+    from oracle import rnampnn_oracle as O
+    hp = dict(DEFAULT_HPARAMS, num_res_neighbours=6, num_res_mpnn_layers=3, padding_len=24, embedding_ffn_dim=128,
+              num_embedding_attn_layers=1, post_fusion_ffn_dim=128, num_raw_ffn_dim=128, readout_hidden_dim=128)
+    lens = [14, 5, 9, 21]
+    coords, mask, labels = synth.synth_batch(lens, first_index=140)
+    model, sd_np = _model(hp, state_dict_shapes(hp), "f32")
+    c, m, y = torch.from_numpy(coords), torch.from_numpy(mask), torch.from_numpy(labels)
+    p, seed = 0.4, 123456789
+    loss, logits = model.loss_and_grad(y, c, m, return_logits=True, dropout=p, seed=seed)
+    g1 = model.flat_grad.clone()
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd_np.items()}
+    ocfg = O.OracleConfig(**{k: v for k, v in hp.items() if k in O.OracleConfig.__dataclass_fields__})
+    ref_logits, _ = O.forward(c, m, sd, ocfg, dropout=p, seed=seed)
+    ref_loss = O.loss_double_softmax(ref_logits, m, y)
+    ref_loss.backward()
+    assert (logits.cpu() - ref_logits.detach()).abs().max() < 2e-4, float((logits.cpu() - ref_logits.detach()).abs().max())
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    eval_logits, _ = O.forward(c, m, {k: v.detach() for k, v in sd.items()}, ocfg)
+    assert (ref_logits.detach() - eval_logits).abs().max() > 1e-3            # the masks really act
+    worst = 0.0
+    for key, prm in model.named_parameters():
+        g = prm.grad.detach().cpu()
+        r = sd[key].grad
+        r = torch.zeros_like(g) if r is None else r
+        err = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-7)
+        worst = max(worst, err)
+        assert err < 2e-3 or float((g - r).abs().max()) < 1e-7, f"{key}: rel grad error {err:.2e}"
+    loss2 = model.loss_and_grad(y, c, m, dropout=p, seed=seed)
+    assert torch.equal(model.flat_grad, g1) and float(loss2) == float(loss)   # bit-reproducible
+    loss3 = model.loss_and_grad(y, c, m, dropout=p, seed=seed + 1)
+    assert float(loss3) != float(loss)
+    print(f"dropout {p}: loss {float(loss):.6f}, worst relative gradient error {worst:.2e}")
+
+
+def test_autograd_training_step_matches_native_loss_and_grad():
+    """The reference's training_step (rnampnn.py:187-207) is drop-in: ``loss = model.training_step(batch);
+    loss.backward()`` on the autograd-visible forward gives the loss and gradients of the one-call native path
+    (same seed), gradients accumulate across backward calls like torch's, and optimizer.zero_grad() resets them."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    coords, mask, labels = synth.synth_batch([24, 17, 30, 12], first_index=70)
+    model = RNAMPNN(precision="f32", num_res_neighbours=8, num_res_mpnn_layers=2, padding_len=32).to("cuda:0")
+    model.train()
+    (opt,), _ = model.configure_optimizers()
+    c, m, y = torch.from_numpy(coords), torch.from_numpy(mask), torch.from_numpy(labels)
+    onehot = torch.nn.functional.one_hot(y, 4).float()
+    model.manual_seed(7)
+    native = model.loss_and_grad(y, c, m)                      # train mode: dropout 0.4, seed (7 << 32) + 1
+    g_native = model.flat_grad.clone()
+    opt.zero_grad()
+    model.manual_seed(7)
+    loss = model.training_step((onehot, c, m, ["a", "b", "c", "d"]))
+    assert loss.requires_grad
+    loss.backward()
+    assert abs(float(loss) - float(native)) < 1e-6
+    assert (model.flat_grad - g_native).abs().max() <= 1e-6 * (1 + float(g_native.abs().max()))
+    assert all(p.grad is not None and p.grad.data_ptr() >= model.flat_grad.data_ptr() for p in model.parameters())
+    model.manual_seed(7)
+    model.training_step((onehot, c, m, None)).backward()       # second backward without zero_grad: accumulates
+    assert (model.flat_grad - 2 * g_native).abs().max() <= 1e-5 * (1 + float(g_native.abs().max()))
+    before = model.readout.readout_layers._modules["0"].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.readout.readout_layers._modules["0"].weight.detach())
+    model.eval()
+    with torch.no_grad():
+        out = model(c, m)
+    assert not out.requires_grad
 
 
 def test_training_loop_reduces_loss():
@@ -460,7 +551,7 @@ def test_full_size_properties_c2():
     assert (a[:6].cpu() - ref).abs().max() < BF16_LOGIT_TOL
 
 
-@pytest.mark.parametrize("k", [4, 5, 7, 9, 16, 17, 25, 31])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 9, 16, 17, 25, 31])
 def test_bf16_fast_path_tracks_f32_path_across_neighbourhood_sizes(k):
     """The fused bf16 kernel has two block shapes (k > 16: one residue per 32-edge block; k <= 16: 32 / k residues per
     block with the multi-residue P injection) and padding slots when k does not divide 32: every shape must stay

@@ -5,10 +5,11 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
+python3 $ROOT/__graft_entry__.py || exit 1    # build OUTSIDE the profiler (a hipcc child of a profiled process is a forbidden exec hop)
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "${EXTRA[@]}" > $OUT/$name.log 2>&1
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --no-build --steps 2 --warmup 1 --no-cpu-baseline "${EXTRA[@]}" > $OUT/$name.log 2>&1
   echo "$name exit $?"
 }
 EXTRA=("$@")
