@@ -410,7 +410,7 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
 // ------------------------------------------------------------------------------------------
 struct Ws {                       // workspace carve (all offsets 256-byte aligned)
     int *len, *cu, *node_b, *nbr;
-    float *geom, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
+    float *geom, *geomh, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
     float* coef;                  // fast path: per-RNA GraphNorm affine coefficients [B][256]
     bf16_t *q_e, *q_m;            // fast path: bf16 Q tables [(Nmax+1)][128]; pq_* then hold P as [(Nmax+1)][128] f32
     void* e;                      // f32 or bf16 [Nmax*k][128]
@@ -430,6 +430,7 @@ static size_t carve(const rnampnn_ctx* c, int B, size_t Nmax, char* base, Ws* w)
     r.node_b = (int*)take(Nmax * sizeof(int));
     r.nbr = (int*)take(Nmax * k * sizeof(int));
     r.geom = (float*)take((Nmax + B) * RN_GEOM * sizeof(float));
+    r.geomh = (float*)take(c->cfg.precision == RNAMPNN_PREC_BF16 ? (Nmax + B) * RN_GEOMH * sizeof(float) : 0);
     r.raw_p = (float*)take(Nmax * RN_RAWP * sizeof(float));
     r.hA = (float*)take((Nmax + 1) * RN_D * sizeof(float));
     r.hB = (float*)take((Nmax + 1) * RN_D * sizeof(float));
@@ -665,11 +666,11 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
     hipStream_t s = r.s;
 
     // ---- ResFeature.forward (feature.py:588-592)
-    launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, s);
+    launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, r.fast ? w.geomh : nullptr, s);
     if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s))
         return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
     if (r.fast)
-        launch_edge_embed_bf16(r.pk, k, w.geom, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
+        launch_edge_embed_bf16(r.pk, k, w.geomh, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
                                derp<float>(c, c->edge_embed_b1p), (bf16_t*)w.e, s);
     else
         launch_edge_embed_f32(r.pk, k, w.geom, w.nbr, derp<float>(c, c->edge_embed[0].wt), rawp(c, c->edge_embed[0].b),

@@ -242,10 +242,16 @@ void launch_build_mlp_image(const float* wc, int ld_wc, const float* w2, int ld_
 // order (EMB_SLOTS slots per half, 7 k-steps of 16): slot p of half h sits at k = 16*(p>>3) + 8h + (p&7).
 #define EMB_KS 7
 #define EMB_SLOTS 56
+// Lane half h owns the NEIGHBOUR items 4h..4h+3 (atoms), 3h..3h+2 (unit bonds), 2h, 2h+1 (unit normals) - what its 28
+// floats of the half-split geometry record hold (kernels_f32.hip: geomh_record) - against ALL central items:
+//   p <  28: distance  central atom a = p >> 2   to neighbour atom   4h + (p & 3)        -> feature a*7 + b        (feature.py:414-418)
+//   p <  43: cosine    central bond a = (p-28)/3 to neighbour bond   3h + (p-28) % 3     -> feature 49 + a*5 + b   (feature.py:451-464)
+//   p <  51: cosine    central normal a = (p-43)>>1 to neighbour normal 2h + ((p-43)&1)  -> feature 74 + a*4 + b   (feature.py:493-512)
+// slots of items a half does not have (atom 7, bond 5) and p >= 51 carry zero weights.
 __host__ __device__ __forceinline__ int emb_feature_of_slot(int h, int p) {      // -> original feature id or -1
-    if (p < 28) { int a = 4 * h + p / 7, b = p % 7; return a <= 6 ? a * 7 + b : -1; }
-    if (p < 43) { int q = p - 28, ai = q / 5, b = q % 5, a = 2 * h + ai; return (h == 0 ? ai < 2 : a <= 4) ? 49 + a * 5 + b : -1; }
-    if (p < 51) { int q = p - 43, a = 2 * h + q / 4, b = q % 4; return 74 + a * 4 + b; }
+    if (p < 28) { int a = p >> 2, b = 4 * h + (p & 3); return b <= 6 ? a * 7 + b : -1; }
+    if (p < 43) { int q = p - 28, a = q / 3, b = 3 * h + q % 3; return b <= 4 ? 49 + a * 5 + b : -1; }
+    if (p < 51) { int q = p - 43, a = q >> 1, b = 2 * h + (q & 1); return 74 + a * 4 + b; }
     return -1;
 }
 __global__ void k_build_embed_image(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -852,16 +858,28 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
 }
 
 // ------------------------------------------------------------------------------------------
-// Edge featurisation + embedding MLP on MFMA (feature.py:386-571): each lane computes the
-// EMB_SLOTS raw features of its (edge, half) from the two geometry records straight into the
-// B fragments of Linear(90,128) (the 90-wide tensor exists only in registers), then
-// GELU -> Linear(128,128) -> GELU -> e0 in bf16 (16-byte stores); invalid slots store 0.
-__global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, const float* __restrict__ geom,
+// Edge featurisation + embedding MLP on MFMA (feature.py:386-571).  One wave per 32-edge block; lane (r, h) = (edge r,
+// k-half h) computes the EMB_SLOTS raw features of its half (emb_feature_of_slot) straight into the B fragments of
+// Linear(90,128) - the 90-wide tensor exists only in registers - then GELU -> Linear(128,128) -> GELU -> e0 in bf16
+// (16-byte stores, fragment-major); absent edges and padding slots store zeros.
+//   * the CENTRAL residue of a block is wave-uniform (k > 16: one residue per block): its record is read with scalar
+//     loads and enters the vector arithmetic as SGPR operands - no per-lane loads, no address arithmetic, no selects;
+//   * of the NEIGHBOUR's record each lane half gathers only the 28 floats (7 x 16 B) of the items it owns;
+//   * the loop is software-pipelined on its only dependent memory chain: the neighbour index of block i+2 and the
+//     neighbour record of block i+1 are requested while block i runs through the matrix pipe;
+//   * no divergent branch: validity is an AND mask on the packed output words.
+#ifdef RN_EE_NOFENCE
+#define RN_EE_FENCE() do { } while (0)
+#else
+#define RN_EE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <bool SMALLK>
+__global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, const float* __restrict__ geomh,
         const int* __restrict__ nbr, const bf16_t* __restrict__ img_g, const float* __restrict__ b0,
         const float* __restrict__ b1p, bf16_t* __restrict__ e) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img = reinterpret_cast<u32x4*>(smem);
-    const int NFRAG = 4 * EMB_KS + 32;
+    constexpr int NFRAG = 4 * EMB_KS + 32;
     const int tid = threadIdx.x;
     float* lds_b = reinterpret_cast<float*>(smem + (size_t)NFRAG * 1024);      // both bias vectors: a global read per channel block
     if (tid < 128) lds_b[tid] = b0[tid];                                        // of every edge block would expose an L2 round trip each
@@ -869,51 +887,68 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
     {   // 60 KiB image: loads of a thread first, LDS writes after (see stage_image)
         u32x4 t[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (tid + i * 512 < NFRAG * 64) t[i] = reinterpret_cast<const u32x4*>(img_g)[tid + i * 512];
+        for (int i = 0; i < 8; ++i) t[i] = reinterpret_cast<const u32x4*>(img_g)[min(tid + i * 512, NFRAG * 64 - 1)];
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (tid + i * 512 < NFRAG * 64) img[tid + i * 512] = t[i];
     }
     __syncthreads();
     const int ntot = pk.cu[pk.B];
-    const int npb = k > 16 ? 1 : 32 / k;
+    const int npb = SMALLK ? 32 / k : 1;
     const int nblocks = (ntot + npb - 1) / npb;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int q0 = SMALLK ? r / k : 0;
+    const bool slot_ok = SMALLK ? q0 < npb : r < k;
+    const int last_idx = ntot * k - 1;
+    const int stride = gridDim.x * 8;
 
-    for (int blk = blockIdx.x * 8 + wave; blk < nblocks; blk += gridDim.x * 8) {
-        BlockLane bl = block_lane(blk, npb, k, ntot, r, nbr);
-        const int inode = bl.ok ? bl.node : 0;
-        const float* gi = geom + (size_t)inode * RN_GEOM;
-        const float* gj = geom + (size_t)(bl.valid ? bl.j : inode) * RN_GEOM;
-        float cj[RN_GEOM];
+    // neighbour row of this lane's edge in block b (-1: no edge), addresses clamped, loads unconditional
+    auto load_j = [&](int b) -> int {
+        const int i = b * npb * k + r;
+        const int jr = nbr[min(max(i, 0), max(last_idx, 0))];
+        return (b < nblocks && slot_ok && b * npb + q0 < ntot) ? jr : -1;
+    };
+    f32x4 nrec[7];
+    auto load_rec = [&](int j) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(geomh + (size_t)(j >= 0 ? j : 0) * RN_GEOMH + 32 * h);
 #pragma unroll
-        for (int v = 0; v < RN_GEOM / 4; ++v) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(gj + 4 * v);
-            cj[4 * v] = t[0]; cj[4 * v + 1] = t[1]; cj[4 * v + 2] = t[2]; cj[4 * v + 3] = t[3];
-        }
+        for (int v = 0; v < 7; ++v) nrec[v] = src[v];
+    };
+    int blk = blockIdx.x * 8 + wave;
+    if (blk >= nblocks) return;
+    int j_cur = load_j(blk), j_nxt = load_j(blk + stride);
+    load_rec(j_cur);
+
+    for (; blk < nblocks; blk += stride) {
+        // ---- central record: wave-uniform pointer (k > 16) -> scalar loads; per-lane pointer otherwise
+        const int cnode = SMALLK ? min(blk * npb + q0, ntot - 1) : __builtin_amdgcn_readfirstlane(blk);
+        const float* __restrict__ gc = geomh + (size_t)cnode * RN_GEOMH;
+        auto catom = [&](int a, int d) { return a < 4 ? gc[3 * a + d] : gc[32 + 3 * (a - 4) + d]; };
+        auto cbond = [&](int a, int d) { return a < 3 ? gc[12 + 3 * a + d] : gc[32 + 12 + 3 * (a - 3) + d]; };
+        auto cnorm = [&](int a, int d) { return a < 2 ? gc[21 + 3 * a + d] : gc[32 + 21 + 3 * (a - 2) + d]; };
+        float nl[28];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) { nl[4 * v] = nrec[v][0]; nl[4 * v + 1] = nrec[v][1]; nl[4 * v + 2] = nrec[v][2]; nl[4 * v + 3] = nrec[v][3]; }
         float ft[EMB_SLOTS];
 #pragma unroll
-        for (int ai = 0; ai < 4; ++ai) {                       // distances: central atoms 4h .. 4h+3
-            int a = 4 * h + ai; a = a > 6 ? 6 : a;
-            float ax = gi[a * 3], ay = gi[a * 3 + 1], az = gi[a * 3 + 2];
+        for (int a = 0; a < 7; ++a) {                          // 28 distances
+            const float ax = catom(a, 0), ay = catom(a, 1), az = catom(a, 2);
 #pragma unroll
-            for (int b = 0; b < 7; ++b) {
-                float dx = ax - cj[b * 3], dy = ay - cj[b * 3 + 1], dz = az - cj[b * 3 + 2];
-                ft[ai * 7 + b] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz + kSEPS);
+            for (int bl = 0; bl < 4; ++bl) {
+                const float dx = nl[3 * bl] - ax, dy = nl[3 * bl + 1] - ay, dz = nl[3 * bl + 2] - az;
+                ft[4 * a + bl] = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, kSEPS))));
             }
         }
 #pragma unroll
-        for (int ai = 0; ai < 3; ++ai) {                       // bond cosines: central bonds 2h .. 2h+2
-            int a = 2 * h + ai; a = a > 4 ? 4 : a;
-            float ax = gi[21 + a * 3], ay = gi[22 + a * 3], az = gi[23 + a * 3];
+        for (int a = 0; a < 5; ++a) {                          // 15 bond cosines
+            const float ax = cbond(a, 0), ay = cbond(a, 1), az = cbond(a, 2);
 #pragma unroll
-            for (int b = 0; b < 5; ++b) ft[28 + ai * 5 + b] = ax * cj[21 + b * 3] + ay * cj[22 + b * 3] + az * cj[23 + b * 3];
+            for (int bl = 0; bl < 3; ++bl) ft[28 + 3 * a + bl] = fmaf(az, nl[12 + 3 * bl + 2], fmaf(ay, nl[12 + 3 * bl + 1], ax * nl[12 + 3 * bl]));
         }
 #pragma unroll
-        for (int ai = 0; ai < 2; ++ai) {                       // normal cosines: central normals 2h, 2h+1
-            int a = 2 * h + ai;
-            float ax = gi[36 + a * 3], ay = gi[37 + a * 3], az = gi[38 + a * 3];
+        for (int a = 0; a < 4; ++a) {                          // 8 normal cosines
+            const float ax = cnorm(a, 0), ay = cnorm(a, 1), az = cnorm(a, 2);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) ft[43 + ai * 4 + b] = ax * cj[36 + b * 3] + ay * cj[37 + b * 3] + az * cj[38 + b * 3];
+            for (int bl = 0; bl < 2; ++bl) ft[43 + 2 * a + bl] = fmaf(az, nl[21 + 3 * bl + 2], fmaf(ay, nl[21 + 3 * bl + 1], ax * nl[21 + 3 * bl]));
         }
 #pragma unroll
         for (int p = 51; p < EMB_SLOTS; ++p) ft[p] = 0.f;
@@ -922,7 +957,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         for (int s = 0; s < EMB_KS; ++s)
 #pragma unroll
             for (int t = 0; t < 4; ++t) xf[s][t] = pack2(ft[8 * s + 2 * t], ft[8 * s + 2 * t + 1]);
-        __builtin_amdgcn_sched_barrier(0);
+        RN_EE_FENCE();
+        // ---- requests of the next two blocks (their latency passes under this block's matrix work)
+        const unsigned vmask = j_cur >= 0 ? 0xffffffffu : 0u;
+        load_rec(j_nxt);
+        j_cur = j_nxt;
+        j_nxt = load_j(blk + 2 * stride);
+        RN_EE_FENCE();
 
         u32x4 hb[8];
 #pragma unroll
@@ -937,7 +978,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
                 hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
                 hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
             }
-            __builtin_amdgcn_sched_barrier(0);
+            RN_EE_FENCE();
         }
         u32x4* ewp = efrag_ptr(e, blk, lane);
 #pragma unroll
@@ -951,17 +992,17 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
                     const f16x4 ph = phi4(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
-                    nw[t] = bl.valid ? pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) : 0u;
-                    nw[t + 1] = bl.valid ? pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) : 0u;
+                    nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) & vmask;
+                    nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) & vmask;
                 }
                 ewp[64 * (2 * ob + sp)] = nw;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            RN_EE_FENCE();
         }
     }
 }
 
-void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const int* nbr, const bf16_t* img,
+void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geomh, const int* nbr, const bf16_t* img,
                             const float* b0, const float* b1p, bf16_t* e, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
@@ -969,7 +1010,8 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     if (grid < 1) grid = 1;
     size_t lds = (size_t)(4 * EMB_KS + 32) * 1024 + 1024;
-    hipLaunchKernelGGL(k_edge_embed_bf16, dim3(grid), dim3(512), lds, s, pk, k, geom, nbr, img, b0, b1p, e);
+    if (k > 16) hipLaunchKernelGGL(k_edge_embed_bf16<false>, dim3(grid), dim3(512), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
+    else hipLaunchKernelGGL(k_edge_embed_bf16<true>, dim3(grid), dim3(512), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -128,6 +128,32 @@ __device__ __forceinline__ void geom_record(const float* c, float* g) {
     }
 }
 
+// The same record split by LANE HALF for the bf16 edge-embedding kernel (RN_GEOMH = 64 floats = 256 B, so a record never
+// straddles more than two 128-B lines): half h (floats 32h ..) = atoms 4h..4h+3 (12) | unit bonds 3h..3h+2 (9) |
+// unit normals 2h, 2h+1 (6) | zeros (5); the items a half does not have (atom 7, bond 5) are zeros.  Lane half h of the
+// kernel gathers only ITS 28 floats of the neighbour (7 x 16 B), the central residue's record is read with scalar loads.
+__device__ __forceinline__ void geomh_record(const float* g, float* gh) {
+#pragma unroll
+    for (int i = 0; i < RN_GEOMH; ++i) gh[i] = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (4 * h + a < 7)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gh[32 * h + 3 * a + d] = g[(4 * h + a) * 3 + d];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (3 * h + a < 5)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gh[32 * h + 12 + 3 * a + d] = g[21 + (3 * h + a) * 3 + d];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) gh[32 * h + 21 + 3 * a + d] = g[36 + (2 * h + a) * 3 + d];
+    }
+}
+
 __device__ __forceinline__ void raw_features(const float* c, float* f) {
     int o = 0;
 #pragma unroll
@@ -163,8 +189,15 @@ __device__ __forceinline__ void raw_features(const float* c, float* f) {
     for (int a = 0; a < 3; ++a) f[25 + a] = nm[a + 1][0] * nm[a][0] + nm[a + 1][1] * nm[a][1] + nm[a + 1][2] * nm[a][2];
 }
 
+__device__ __forceinline__ void store_geomh(const float* g, float* __restrict__ dst) {
+    float gh[RN_GEOMH];
+    geomh_record(g, gh);
+#pragma unroll
+    for (int i = 0; i < RN_GEOMH; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(gh[i], gh[i + 1], gh[i + 2], gh[i + 3]);
+}
+
 __global__ void k_geom(const float* __restrict__ coords, PackInfo pk, float* __restrict__ raw_out,
-                       float* __restrict__ raw_p, float* __restrict__ geom) {
+                       float* __restrict__ raw_p, float* __restrict__ geom, float* __restrict__ geomh) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= pk.B * pk.T) return;
     int b = id / pk.T, t = id - b * pk.T;
@@ -195,6 +228,7 @@ __global__ void k_geom(const float* __restrict__ coords, PackInfo pk, float* __r
         float* gp = geom + (size_t)p * RN_GEOM;
 #pragma unroll
         for (int i = 0; i < RN_GEOM; ++i) gp[i] = g[i];
+        if (geomh) store_geomh(g, geomh + (size_t)p * RN_GEOMH);
     } else {
         if (raw_out) {                                          // padded rows: 1e6 distances, 0 cosines
             float* ro = raw_out + (size_t)id * RN_RAW;
@@ -209,13 +243,14 @@ __global__ void k_geom(const float* __restrict__ coords, PackInfo pk, float* __r
             float* gp = geom + (size_t)(pk.Nmax + b) * RN_GEOM;
 #pragma unroll
             for (int i = 0; i < RN_GEOM; ++i) gp[i] = g[i];
+            if (geomh) store_geomh(g, geomh + (size_t)(pk.Nmax + b) * RN_GEOMH);
         }
     }
 }
 
-void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, hipStream_t s) {
+void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, float* geomh, hipStream_t s) {
     int total = pk.B * pk.T;
-    hipLaunchKernelGGL(k_geom, dim3((total + 63) / 64), dim3(64), 0, s, coords, pk, raw_out, raw_p, geom);
+    hipLaunchKernelGGL(k_geom, dim3((total + 63) / 64), dim3(64), 0, s, coords, pk, raw_out, raw_p, geom, geomh);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #define RN_ERAW 90          // edge raw features
 #define RN_ERAWP 96
 #define RN_GEOM 48          // per-residue geometry record: 21 coords, 15 unit bonds, 12 unit normals
+#define RN_GEOMH 64         // the same record split by lane half for the bf16 edge-embedding kernel (kernels_f32.hip: geomh_record)
 #define RN_KMAX 32
 
 typedef unsigned short bf16_t;   // raw bf16 bits
@@ -56,7 +57,7 @@ struct ZeroRegions { void* ptr[8]; unsigned words[8]; int n; };       // 4-byte 
 void launch_zero_regions(const ZeroRegions& z, hipStream_t s);
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s);
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s);
-void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, hipStream_t s);
+void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, float* geomh, hipStream_t s);
 int  launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t* edge_index_out, hipStream_t s);
 void launch_edge_embed_f32(const PackInfo& pk, int k, const float* geom, const int* nbr,
                            const float* w0t, const float* b0, const float* w1t, const float* b1, int depth,
