@@ -296,9 +296,10 @@ def train_leg(args, model, dev_batches, n_steps, world, dev, red_dev, barrier, d
         tr = None
     else:
         from rnampnn.model.rnampnn import RNAMPNN
-        tr = RNAMPNN(precision="f32", **{kk: model.hparams[kk] for kk in ("num_res_neighbours", "padding_len")}).to(dev)
+        tr = RNAMPNN(precision=args.precision, **{kk: model.hparams[kk] for kk in ("num_res_neighbours", "padding_len")}).to(dev)
         tr.load_state_dict(model.state_dict())
-        (opt,), _ = tr.configure_optimizers()
+        tr.train()                                  # dropout 0.4 active, as the reference trains
+        (opt,), _ = tr.configure_optimizers(fused=True)
 
     def one():
         nonlocal ar_ms
@@ -329,7 +330,8 @@ def train_leg(args, model, dev_batches, n_steps, world, dev, red_dev, barrier, d
     el = time.perf_counter() - t0
     t_max, nt_total = shard.reduce_job(el, nt, red_dev)
     return {"value": nt_total * n_steps / t_max, "unit": "nucleotides/s (training step: fwd + bwd + all-reduce + Adam)",
-            "steps": n_steps, "ms_per_step": t_max / n_steps * 1e3, "rnas_per_rank_per_step": nb, "dtype": "f32",
+            "steps": n_steps, "ms_per_step": t_max / n_steps * 1e3, "rnas_per_rank_per_step": nb,
+            "dtype": "bf16-mixed (MFMA GEMMs, f32 accumulate / elementwise)" if args.precision == "bf16" else "f32",
             "allreduce_ms_per_step": ar_ms / n_steps if world > 1 else None, "allreduce_bytes": 3536900 * 4}
 
 

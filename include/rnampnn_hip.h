@@ -186,14 +186,24 @@ int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, i
 size_t  rnampnn_train_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
 int64_t rnampnn_grad_numel(rnampnn_handle h);
 int     rnampnn_weight_offset(rnampnn_handle h, int32_t i, int64_t* offset);
+#define RNAMPNN_TRAIN_F32        0  /* exact-f32 GEMMs: the parity-grade path (gradients vs oracle autograd to 2e-3)         */
+#define RNAMPNN_TRAIN_BF16_MIXED 1  /* the reference's `bf16-mixed` (rnampnn/utils/train.py:109): GEMM operands bf16 on MFMA, */
+                                    /* f32 accumulate, everything else f32                                                    */
 int     rnampnn_train_forward(rnampnn_handle h, const float* coords, const float* mask, int32_t B, int32_t T,
-                              int32_t T_norm, float dropout, uint64_t seed, float* logits,
+                              int32_t T_norm, float dropout, uint64_t seed, int32_t flags, float* logits,
                               void* workspace, size_t workspace_bytes, void* stream);
 int     rnampnn_train_backward(rnampnn_handle h, const float* dlogits, int32_t B, int32_t T, int32_t accumulate,
                                float* grad, void* workspace, size_t workspace_bytes, void* stream);
 int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float* mask, const int32_t* labels,
-                              int32_t B, int32_t T, int32_t T_norm, float dropout, uint64_t seed, float* loss,
-                              float* logits, float* grad, void* workspace, size_t workspace_bytes, void* stream);
+                              int32_t B, int32_t T, int32_t T_norm, float dropout, uint64_t seed, int32_t flags,
+                              float* loss, float* logits, float* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* Optimiser support (F2).  rnampnn_use_weight_arena: the caller's flat f32 buffer (rnampnn_grad_numel() elements, tensor i
+ * at rnampnn_weight_offset(i)) becomes the library's weight storage - the nn.Parameters of the Python module are views
+ * of it, so an optimiser step needs no re-upload.  rnampnn_adam_step: torch.optim.Adam (betas, eps, L2 weight decay:
+ * rnampnn.py:156-159) as ONE launch over the flat parameter / gradient / moment buffers; `step` counts from 1. */
+int     rnampnn_use_weight_arena(rnampnn_handle h, float* arena, void* stream);
+int     rnampnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 /* -- measurement ------------------------------------------------------------------------- */
 /* Live timing of the dominant kernel (the fused ResMPNN edge kernel, mpnn.py:154-265): when

@@ -99,6 +99,8 @@ struct rnampnn_ctx {
     float tape_p = 0.f;
     uint64_t tape_seed = 0;
     const void* tape_ws = nullptr;
+    bool tape_mixed = false;
+    bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
 };
 
 static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {
@@ -302,7 +304,7 @@ extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t
 extern "C" int rnampnn_destroy(rnampnn_handle h) {
     if (!h) return RNAMPNN_OK;
     for (auto& e : h->ev) (void)hipEventDestroy(e);
-    if (h->raw_arena) (void)hipFree(h->raw_arena);
+    if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
     if (h->der_arena) (void)hipFree(h->der_arena);
     delete h;
     return RNAMPNN_OK;
@@ -322,7 +324,11 @@ extern "C" int rnampnn_set_weight(rnampnn_handle h, const char* key, const float
     if (!h || !key || !data) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_set_weight: null argument");
     if (!h->raw_arena) {
         HIP_TRY(hipMalloc((void**)&h->raw_arena, h->raw_floats * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(h->raw_arena, 0, h->raw_floats * sizeof(float), (hipStream_t)stream));
+    }
+    if (!h->der_arena) {
         HIP_TRY(hipMalloc((void**)&h->der_arena, h->der_bytes));
+        HIP_TRY(hipMemsetAsync(h->der_arena, 0, h->der_bytes, (hipStream_t)stream));
     }
     for (auto& t : h->raw) {
         if (t.key == key) {
@@ -337,6 +343,24 @@ extern "C" int rnampnn_set_weight(rnampnn_handle h, const char* key, const float
         }
     }
     return fail(RNAMPNN_ERR_WEIGHTS, "unknown state_dict key '%s'", key);
+}
+
+// The caller's flat f32 buffer of rnampnn_grad_numel() elements becomes the weight storage itself (tensor i at
+// rnampnn_weight_offset(i)): an optimiser that updates it in place needs no upload, only rnampnn_finalize_weights
+// before the next INFERENCE call (the bf16-mixed training kernels read nn.Linear.weight as stored).
+extern "C" int rnampnn_use_weight_arena(rnampnn_handle h, float* arena, void* stream) {
+    if (!h || !arena) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_use_weight_arena: null argument");
+    if (((uintptr_t)arena & 15) != 0) return fail(RNAMPNN_ERR_BAD_ARG, "weight arena must be 16-byte aligned");
+    if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
+    h->raw_arena = arena;
+    h->raw_external = true;
+    if (!h->der_arena) {
+        HIP_TRY(hipMalloc((void**)&h->der_arena, h->der_bytes));
+        HIP_TRY(hipMemsetAsync(h->der_arena, 0, h->der_bytes, (hipStream_t)stream));
+    }
+    for (auto& t : h->raw) t.set = true;
+    h->finalized = false;
+    return RNAMPNN_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -23,6 +23,14 @@ void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, 
 struct TScratch { float* p; size_t floats; };                // partial results of the ordered two-stage reductions
 void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
                const TScratch& sc, hipStream_t s);                                                           // dW += A^T B
+// bf16-mixed MFMA versions (kernels_train.hip, second half).  _nt / _nn return false when the shape is not covered
+// (K not a multiple of 16, unaligned rows): the caller then uses the f32 kernel.
+bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s);
+bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                int ldy, int beta, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s);
+void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
+                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, hipStream_t s);
 void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s);   // out += column sums
 void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, const TDrop& dr, unsigned site, hipStream_t s);   // y = drop(gelu(x))
 void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site,
@@ -51,3 +59,5 @@ int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int 
 void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlogits_p, hipStream_t s);
 void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, const TScratch& sc,
                  hipStream_t s);
+void t_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                 int step, hipStream_t s);

@@ -640,3 +640,216 @@ void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlog
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_unpack_dlogits, dim3(grid), dim3(256), 0, s, pk, dlogits_padded, dlogits_p);
 }
+
+// ==========================================================================================
+// bf16-MIXED training GEMMs on MFMA (the reference trains under bf16 autocast, rnampnn/utils/train.py:109: matmul
+// operands bf16, accumulation and everything else f32).  f32 tensors in HBM, converted to bf16 while the operand
+// fragments are loaded - straight from global memory into registers: every flavour below has one operand whose
+// k index runs along ROWS of a row-major tensor (a transposed read), which an LDS staging pass would have to
+// scatter element by element, while a fragment is just 8 coalesced dword loads per lane (lane = row / column of the
+// tile, the wave covers 32 consecutive floats of 8 rows); reuse across waves comes out of L1/L2.
+// v_mfma_f32_32x32x16_bf16: A fragment lane (r, h) = A[row r][k = 8h + j], B fragment = B[k = 8h + j][col r].
+// Optional fused element-wise work (saves whole passes over the [E][128] f32 tape):
+//   operand prologue  a = drop(gelu(pre))         (GELU + dropout of a taped pre-activation, never materialised)
+//   result epilogue   y = acc * gelu'(pre) * mask (backward through GELU + dropout)
+typedef __attribute__((ext_vector_type(8))) __bf16 tbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 tbf16x2;
+typedef __attribute__((ext_vector_type(2))) float tf32x2;
+typedef __attribute__((ext_vector_type(4))) float tf32x4;
+typedef __attribute__((ext_vector_type(16))) float tf32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned tu32x4;
+__device__ __forceinline__ unsigned tpack2(float a, float b) {
+    tf32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tbf16x2));
+}
+__device__ __forceinline__ tf32x16 tmfma(tu32x4 a, tu32x4 b, tf32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tbf16x8, a), __builtin_bit_cast(tbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ tu32x4 tpack8(const float (&v)[8]) {
+    return tu32x4{tpack2(v[0], v[1]), tpack2(v[2], v[3]), tpack2(v[4], v[5]), tpack2(v[6], v[7])};
+}
+// fragment whose k index runs along a ROW of src: 8 consecutive floats at src[row][k0 .. k0+7] (two 16-byte loads);
+// act: a = drop(gelu(x)), dropout index row * ld_idx + k
+__device__ __forceinline__ tu32x4 frag_row(const float* __restrict__ src, int ld, int row, int nrows, int k0, bool act,
+                                           const TDrop& dr, unsigned site, int ld_idx) {
+    const bool ok = row < nrows;
+    const float* p = src + (size_t)(ok ? row : 0) * ld + k0;
+    const tf32x4 a = *reinterpret_cast<const tf32x4*>(p), b = *reinterpret_cast<const tf32x4*>(p + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]) * drop_mul(dr, site, (unsigned long long)row * ld_idx + k0 + j);
+    }
+    if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    return tpack8(v);
+}
+// fragment whose k index runs DOWN a column of src: src[k0 + j][col], j = 0..7 (8 dword loads, coalesced across lanes)
+__device__ __forceinline__ tu32x4 frag_col(const float* __restrict__ src, int ld, int k0, int nk, int col, int ncols, bool act,
+                                           const TDrop& dr, unsigned site, int ld_idx) {
+    float v[8];
+    const int cc = col < ncols ? col : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int kk = k0 + j; v[j] = src[(size_t)(kk < nk ? kk : 0) * ld + cc]; }
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]) * drop_mul(dr, site, (unsigned long long)(k0 + j) * ld_idx + col);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (k0 + j >= nk || col >= ncols) v[j] = 0.f;
+    return tpack8(v);
+}
+
+// ---- NT / NN: Y[m][n] (+)= sum_k A[m][k] * B[k][n]  (+ bias[n]) (* gelu'(pre[m][n]) * mask)
+//   A = X rows (k along the row; optional GELU+dropout prologue);  B_NT: B[k][n] = W[n][k] (W row-major [N][K]);
+//   B_NN: B[k][n] = W[k][n] (W row-major [K][N]).  Wave tile 64 rows x 128 columns, workgroup = 4 waves = 256 rows.
+template <bool B_ROWS>      // true: NT (B fragment from rows of W[N][K]); false: NN (B fragment from columns of W[K][N])
+__global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict__ X, int ldx, int K, const float* __restrict__ W, int ldw,
+        const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
+        int ld_epi, TDrop dr, unsigned site) {
+    const int R = nrows(rows);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 256 + wave * 64;
+    if (blockIdx.x * 256 >= R) return;
+    const int n0 = blockIdx.y * 128;
+    tf32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        tu32x4 af[2], bf[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = frag_row(X, ldx, m0 + 32 * a + r, R, k0 + 8 * h, actA != 0, dr, site, K);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (B_ROWS) bf[b] = frag_row(W, ldw, n0 + 32 * b + r, N, k0 + 8 * h, false, dr, 0u, 0);
+            else bf[b] = frag_col(W, ldw, k0 + 8 * h, K, n0 + 32 * b + r, N, false, dr, 0u, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int col = n0 + 32 * b + r;
+        const bool colok = col < N;
+        const float bv = (bias && colok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (colok && row < R) {
+                    float v = acc[a][b][i] + bv;
+                    if (epi_pre) v *= gelu_d(epi_pre[(size_t)row * ld_epi + col]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
+                    float* y = Y + (size_t)row * ldy + col;
+                    *y = beta ? *y + v : v;
+                }
+            }
+        }
+    }
+}
+static bool mm_ok(const void* X, int ldx, int K, const void* W, int ldw, bool b_rows) {
+    return K % 16 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && (!b_rows || (ldw % 4 == 0 && ((uintptr_t)W & 15) == 0));
+}
+// Y = [beta Y] + actA(X) . W^T + bias            (W [N][K] row-major: nn.Linear.weight as it is stored)
+bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s) {
+    if (!mm_ok(X, ldx, K, W, ldw, true)) return false;
+    dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
+    hipLaunchKernelGGL(k_mm<true>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0,
+                       (const float*)nullptr, 0, dr, site);
+    return true;
+}
+// Y = [beta Y] + (X . W) [* gelu'(pre) * mask]    (W [K][N] row-major; backward dX = dY . W with W = nn.Linear.weight [out][in])
+bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                int ldy, int beta, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s) {
+    if (!mm_ok(X, ldx, K, W, ldw, false)) return false;
+    dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
+    hipLaunchKernelGGL(k_mm<false>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, 0, epi_pre, ld_epi, dr, site);
+    return true;
+}
+
+// ---- TN: dW[n][kk] += sum_m A[m][n] * actB(B[m][kk]): contraction over ROWS; both fragments are column reads.
+// Workgroup = 4 waves on one 128 (n) x 128 (kk) output tile: wave = (kk half, row-slice parity); the row range is split
+// over blockIdx.z; every (split, parity) writes its own partial tile, k_reduce_parts adds them in order.
+__global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restrict__ A, int lda, int M, const float* __restrict__ B,
+        int ldb, int K, float* __restrict__ part, int rows_per_split, int actB, TDrop dr, unsigned site) {
+    const int R = nrows(rows);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int half = wave & 1, par = wave >> 1;
+    const int n0 = blockIdx.x * 128, kk0 = blockIdx.y * 128 + 64 * half;
+    const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
+    tf32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    for (int m0 = p_begin + 16 * par; m0 < p_end; m0 += 32) {
+        tu32x4 af[4], bf[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = frag_col(A, lda, m0 + 8 * h, p_end, n0 + 32 * a + r, M, false, dr, 0u, 0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = frag_col(B, ldb, m0 + 8 * h, p_end, kk0 + 32 * b + r, K, actB != 0, dr, site, K);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+    }
+    float* dst = part + ((size_t)blockIdx.z * 2 + par) * M * K;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = kk0 + 32 * b + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = n0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < M && col < K) dst[(size_t)row * K + col] = acc[a][b][i];
+            }
+        }
+}
+void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
+                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, hipStream_t s) {
+    long long cap = (long long)(sc.floats / ((size_t)M * K)) / 2;
+    int splits = (rows.maxrows + 4095) / 4096;
+    if (splits > 256) splits = 256;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    int rps = ((rows.maxrows + splits - 1) / splits + 31) / 32 * 32;
+    dim3 grid((M + 127) / 128, (K + 127) / 128, splits);
+    hipLaunchKernelGGL(k_mm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, rps, actB ? 1 : 0, dr, site);
+    reduce_parts(sc.p, splits * 2, (size_t)M * K, M * K, K, dW, ldw, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam with L2 weight decay, torch.optim.Adam semantics (foreach / fused CUDA form): bias-corrected moments,
+// denom = sqrt(v) / sqrt(1 - beta2^t) + eps.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);       // lerp form of exp_avg
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+void t_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                 int step, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
+}

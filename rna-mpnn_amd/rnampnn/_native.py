@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RNAMPNN_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "librnampnn_hip.so")   # RNAMPNN_LIB: A/B builds of the same ABI (tools/build_variant.sh)
 
 PREC_F32, PREC_BF16 = 0, 1
+TRAIN_F32, TRAIN_BF16_MIXED = 0, 1
 KMAX = 32
 
 ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_T_GT_P, ERR_K_TOO_LARGE, ERR_WORKSPACE, ERR_WEIGHTS, ERR_HIP = 1, 2, 3, 4, 5, 6, 7
@@ -68,9 +69,11 @@ SYMBOLS = {
     "rnampnn_train_workspace_bytes": (_SZ, [_VP, _I32, _I32]),
     "rnampnn_grad_numel": (_I64, [_VP]),
     "rnampnn_weight_offset": (C.c_int, [_VP, _I32, C.POINTER(_I64)]),
-    "rnampnn_train_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _VP, _VP, _SZ, _VP]),
+    "rnampnn_train_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _SZ, _VP]),
+    "rnampnn_use_weight_arena": (C.c_int, [_VP, _VP, _VP]),
+    "rnampnn_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F, _F, _F, _F, _F, _I32, _VP]),
     "rnampnn_train_backward": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _SZ, _VP]),
-    "rnampnn_loss_and_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "rnampnn_loss_and_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_profile_enable": (C.c_int, [_VP, _I32]),
     "rnampnn_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "rnampnn_last_error": (C.c_char_p, []),

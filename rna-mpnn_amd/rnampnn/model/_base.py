@@ -86,7 +86,10 @@ class NativeModule(nn.Module):
                 t.mul_(1.0 / fan_in ** 0.5)
             _register_nested(self, key[len(prefix):], nn.Parameter(t))
         self._handle: Optional[_native.Handle] = None
-        self._synced = None
+        self._param_slices = None
+        self._flat_param: Optional[torch.Tensor] = None
+        self._finalized_sig = None
+        self._ext_version = 0
         self._ws: Optional[torch.Tensor] = None
         self._warned_train = False
 
@@ -98,25 +101,52 @@ class NativeModule(nn.Module):
                                "(there is no CPU fallback)")
         return p.device
 
-    def _ensure(self) -> torch.device:
+    def _bind_flat_params(self, device) -> None:
+        """All parameters are VIEWS of one flat f32 buffer laid out like the library's weight arena, and the library uses
+        that buffer as its weight storage (``rnampnn_use_weight_arena``): an optimiser step - torch's per-tensor Adam or
+        the fused ``FlatAdam`` - updates the weights the kernels read, nothing is re-uploaded.  Re-established whenever a
+        parameter stopped aliasing its slice (``module.to(...)`` replaces ``p.data``)."""
+        lib = _native.lib()
+        if self._param_slices is None:
+            named = dict(self.named_parameters())
+            self._param_slices = []
+            for i, (key, numel) in enumerate(self._handle.weight_schema()):
+                off = C.c_int64()
+                _native.check(lib.rnampnn_weight_offset(self._handle.ptr, i, C.byref(off)))
+                if key.startswith(self._prefix):
+                    self._param_slices.append((named[key[len(self._prefix):]], int(off.value), int(numel)))
+        flat = self._flat_param
+        if flat is not None and flat.device == device and all(p.data_ptr() == flat.data_ptr() + 4 * off
+                                                               for p, off, _ in self._param_slices):
+            return
+        flat = torch.zeros(int(lib.rnampnn_grad_numel(self._handle.ptr)), dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, off, numel in self._param_slices:
+                flat[off: off + numel].copy_(p.data.reshape(-1))
+                p.data = flat[off: off + numel].view(p.shape)
+        with torch.cuda.device(device):
+            _native.check(lib.rnampnn_use_weight_arena(self._handle.ptr, C.c_void_p(flat.data_ptr()), _stream(device)))
+        self._flat_param = flat
+        self._finalized_sig = None
+
+    def _weights_touched(self) -> None:
+        """Called by code that changed the flat parameter buffer behind autograd's back (the fused optimiser)."""
+        self._ext_version += 1
+
+    def _ensure(self, for_mixed_training: bool = False) -> torch.device:
+        """Handle + weight storage ready on the parameters' device.  The kernel-side layouts (K-major f32 copies, bf16
+        fragment images) are rebuilt by ``rnampnn_finalize_weights`` only when the weights changed since the last build AND
+        the caller needs them: the bf16-mixed training kernels read ``nn.Linear.weight`` as stored."""
         device = self._device()
         if self._handle is None:
             self._handle = _native.Handle(self._hp, _PREC[self.precision])
-        named = dict(self.named_parameters())
-        sig = tuple((k, p.data_ptr(), p._version) for k, p in named.items())
-        if sig != self._synced:
-            lib = _native.lib()
-            st = _stream(device)
-            with torch.cuda.device(device):
-                for key, shape in self._shapes.items():
-                    if key.startswith(self._prefix):
-                        src = _prep(named[key[len(self._prefix):]].data, device)
-                    else:
-                        src = torch.zeros(shape, dtype=torch.float32, device=device)
-                    _native.check(lib.rnampnn_set_weight(self._handle.ptr, key.encode(), _ptr(src), src.numel(), 0, st))
-                    src.record_stream(torch.cuda.current_stream(device))
-                _native.check(lib.rnampnn_finalize_weights(self._handle.ptr, st))
-            self._synced = sig
+        self._bind_flat_params(device)
+        if not for_mixed_training:
+            sig = (self._ext_version,) + tuple(p._version for p, _, _ in self._param_slices)
+            if sig != self._finalized_sig:
+                with torch.cuda.device(device):
+                    _native.check(_native.lib().rnampnn_finalize_weights(self._handle.ptr, _stream(device)))
+                self._finalized_sig = sig
         return device
 
     def _workspace(self, B: int, T: int, device) -> torch.Tensor:

@@ -43,6 +43,9 @@ class RNAMPNN(NativeModule):
         self.version = 0
         self._setup(hparams, "", precision)
         self.hparams = dict(self._hp)
+        # GEMM arithmetic of the TRAINING kernels: "bf16" = the reference's bf16-mixed (MFMA, bf16 operands, f32 accumulate),
+        # "f32" = exact (gradient-parity grade).  Follows the inference precision unless set.
+        self.train_precision = self.precision
         self.val_step_outputs = {'val_loss': [], 'correct': [], 'len': [], 'recovery_rates': []}
 
     # ------------------------------------------------------------------ forward surface
@@ -110,16 +113,21 @@ class RNAMPNN(NativeModule):
         aligned = (base + 255) // 256 * 256
         return C.c_void_p(aligned), C.c_size_t(self._tws.numel() - (aligned - base))
 
+    def _train_flags(self) -> int:
+        if self.train_precision not in ("f32", "bf16"):
+            raise ValueError("train_precision must be 'f32' or 'bf16'")
+        return _native.TRAIN_BF16_MIXED if self.train_precision == "bf16" else _native.TRAIN_F32
+
     def _train_forward_native(self, coords, mask, T_norm: int, dropout: float, seed: int) -> torch.Tensor:
-        device = self._ensure()
+        device = self._ensure(for_mixed_training=self.train_precision == "bf16")
         B, T = int(coords.shape[0]), int(coords.shape[1])
         c, m = _prep(coords, device), _prep(mask, device)
         logits = torch.empty(B, T, 4, dtype=torch.float32, device=device)
         with torch.cuda.device(device):
             ws, ws_bytes = self._train_ws(B, T, device)
             _native.check(_native.lib().rnampnn_train_forward(self._handle.ptr, _ptr(c), _ptr(m), B, T, int(T_norm), float(dropout),
-                                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(logits), ws, ws_bytes,
-                                                              _stream(device)))
+                                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), self._train_flags(),
+                                                              _ptr(logits), ws, ws_bytes, _stream(device)))
         return logits
 
     def _train_backward_native(self, dlogits: torch.Tensor) -> None:
@@ -218,7 +226,7 @@ class RNAMPNN(NativeModule):
         collate's one-hot (B,T,4) or class ids (B,T).  Afterwards every ``p.grad`` is a view into ONE flat buffer
         (``self.flat_grad``, overwritten), so a data-parallel job all-reduces gradients with a single RCCL call
         (``allreduce_gradients``)."""
-        device = self._ensure()
+        device = self._ensure(for_mixed_training=self.train_precision == "bf16")
         B, T = int(coords.shape[0]), int(coords.shape[1])
         c, m = _prep(coords, device), _prep(mask, device)
         lab = sequences.argmax(dim=-1) if sequences.dim() == 3 else sequences
@@ -232,7 +240,7 @@ class RNAMPNN(NativeModule):
         with torch.cuda.device(device):
             ws, ws_bytes = self._train_ws(B, T, device)
             _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm), p,
-                                                    C.c_uint64(sd & (2 ** 64 - 1)), _ptr(loss), _ptr(logits),
+                                                    C.c_uint64(sd & (2 ** 64 - 1)), self._train_flags(), _ptr(loss), _ptr(logits),
                                                     _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
         return (loss, logits) if return_logits else loss
 
@@ -284,9 +292,13 @@ class RNAMPNN(NativeModule):
         # rnampnn.py:151-154 - cross_entropy applied to PROBABILITIES (softmax twice), a reference quirk
         return F.cross_entropy(valid_probs, valid_sequences.argmax(dim=-1), reduction='mean')
 
-    def configure_optimizers(self):
-        # rnampnn.py:156-159
-        optimizer = torch.optim.Adam(self.parameters(), lr=self._hp["lr"], weight_decay=self._hp["weight_decay"])
+    def configure_optimizers(self, fused: bool = False):
+        """rnampnn.py:156-159: Adam(lr, weight_decay) + StepLR(15, 0.8).  ``fused=True``: the same update as ONE HIP launch
+        over the flat parameter / gradient buffers (``FlatAdam``) instead of torch's per-tensor kernels."""
+        if fused:
+            optimizer = FlatAdam(self, lr=self._hp["lr"], weight_decay=self._hp["weight_decay"])
+        else:
+            optimizer = torch.optim.Adam(self.parameters(), lr=self._hp["lr"], weight_decay=self._hp["weight_decay"])
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=15, gamma=0.8)
         return [optimizer], [scheduler]
 
@@ -309,6 +321,43 @@ class RNAMPNN(NativeModule):
         self.val_step_outputs['len'].append(n_tot)
         self.val_step_outputs['recovery_rates'] += recovery_rates
         return {'validation loss': loss, 'recovery_rates': recovery_rates}
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` (default betas / eps, L2 weight decay) for an ``RNAMPNN`` whose parameters and gradients are
+    views of two flat buffers: one ``rnampnn_adam_step`` launch per step.  One parameter group, so ``StepLR`` and friends
+    work on it unchanged; ``zero_grad`` zeroes the flat gradient buffer in place (the views stay bound)."""
+
+    def __init__(self, model: "RNAMPNN", lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self.t = 0
+        self.exp_avg = self.exp_avg_sq = None
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        if getattr(self.model, "flat_grad", None) is not None:
+            self.model.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self.model
+        device = m._ensure(for_mixed_training=True)              # parameters aliased to the flat buffer; no finalize here
+        if getattr(m, "flat_grad", None) is None:
+            return loss                                          # no backward has run yet
+        m._bind_flat_grad(device)
+        if self.exp_avg is None or self.exp_avg.device != device:
+            self.exp_avg = torch.zeros_like(m._flat_param)
+            self.exp_avg_sq = torch.zeros_like(m._flat_param)
+        g = self.param_groups[0]
+        self.t += 1
+        with torch.cuda.device(device):
+            _native.check(_native.lib().rnampnn_adam_step(_ptr(m._flat_param), _ptr(m.flat_grad), _ptr(self.exp_avg),
+                                                          _ptr(self.exp_avg_sq), m._flat_param.numel(), float(g["lr"]),
+                                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                          float(g["weight_decay"]), self.t, _stream(device)))
+        m._weights_touched()
+        return loss
 
 
 class _TrainForward(torch.autograd.Function):

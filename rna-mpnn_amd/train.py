@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--dropout", type=float, default=None, help="default: the reference's 0.4 (rnampnn.py:47)")
     ap.add_argument("--nan-policy", default="skip", choices=["skip", "fill"])
+    ap.add_argument("--train-precision", default="bf16", choices=["bf16", "f32"],
+                    help="bf16 = the reference's bf16-mixed trainer setting (utils/train.py:109); f32 = exact")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -79,11 +82,13 @@ def run(args, log=print):
     hp = dict(num_res_neighbours=args.neighbours, num_res_mpnn_layers=args.layers, padding_len=max(args.max_len, 1))
     if args.dropout is not None:
         hp["dropout"] = args.dropout
-    model = RNAMPNN(precision="f32", **hp).to(dev)
+    model = RNAMPNN(**hp).to(dev)
+    model.train_precision = args.train_precision
     if world > 1:                                   # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    (opt,), (sched,) = model.configure_optimizers()
+        model._weights_touched()
+    (opt,), (sched,) = model.configure_optimizers(fused=not args.torch_adam)
     shards = shard.balanced_shards([c.shape[0] for c, _ in train], world)
     mine = shards[rank]
     out = dict(epochs=[], n_train=len(train), n_val=len(val))

@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
-"""Time a few training steps (loss_and_grad) on a C2-shaped batch; used under rocprofv3 for the backward profile."""
+"""Training-step throughput (taped forward + HIP backward + fused Adam) at the C2 shape.
+usage: python tools/train_probe.py [B=64] [precision=bf16|f32] [steps=5]"""
 import os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(REPO, "rna-mpnn_amd")); sys.path.insert(0, REPO)
-import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rna-mpnn_amd"))
+import torch
 from rnampnn.model.rnampnn import RNAMPNN
 from rnampnn.utils import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 lens = synth.synth_lengths(B, 100, 140, seed=0)
 coords, mask, labels = synth.synth_batch(lens)
-model = RNAMPNN(precision="f32", num_res_neighbours=30, padding_len=int(mask.shape[1])).to("cuda").eval()
+model = RNAMPNN(precision=prec, num_res_neighbours=30, padding_len=int(mask.shape[1])).to("cuda:0").train()
+(opt,), _ = model.configure_optimizers(fused=True)
 c, m, y = (torch.from_numpy(a).cuda() for a in (coords, mask, labels))
-model.loss_and_grad(y, c, m); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
+for it in range(steps + 2):
+    if it == 2:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
     loss = model.loss_and_grad(y, c, m)
+    opt.step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"train step: B={B} nt={int(lens.sum())} {dt*1e3:.1f} ms/step -> {lens.sum()/dt:.0f} nt/s, loss {float(loss):.4f}")
+print(f"train step {prec}: B={B} nt={int(lens.sum())}  {dt * 1e3:.1f} ms/step  {int(lens.sum()) / dt:.0f} nt/s  loss {float(loss):.4f}")
