@@ -57,7 +57,7 @@ class OracleConfig:
 # ----------------------------------------------------------------------------- dropout (train mode)
 # The reference applies nn.Dropout(p) after every GELU (mpnn.py:140,150; feature.py:200; functional.py:69,124,184)
 # and dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), functional.py:109), with masks from
-# torch's global RNG.  The HIP training path draws the keep decision of an element from a counter hash of
+# torch's global RNG.  The HIP training path draws the keep decision of an element from a 32-bit counter hash of
 # (seed, site, element index) instead (csrc/kernels_train.h: TDrop); this class restates that hash so oracle autograd
 # and the HIP backward see the same masks.  element index = row * D + channel, rows in the packed order of the valid
 # residues (node row p = cu[b] + t, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
@@ -73,17 +73,20 @@ def site_edge(layer: int, i: int) -> int:
 
 
 def dropout_multiplier(seed: int, site: int, idx, p: float):
-    """-> float32 numpy array of 0 or 1/(1-p) for the element indices ``idx`` (any integer array)."""
+    """-> float32 numpy array of 0 or 1/(1-p) for the element indices ``idx`` (any integer array): the 32-bit counter hash
+    of csrc/kernels_train.hip (drop_mul), all arithmetic modulo 2^32."""
     import numpy as np
-    m64 = (1 << 64) - 1
+    u32 = np.uint32
+    i64 = np.asarray(idx).astype(np.uint64)
+    lo, hi = (i64 & np.uint64(0xFFFFFFFF)).astype(u32), (i64 >> np.uint64(32)).astype(u32)
+    const = (int(site) * 0x85EBCA6B + (int(seed) & 0xFFFFFFFF) + ((int(seed) >> 32) & 0xFFFFFFFF) * 0x27D4EB2F) & 0xFFFFFFFF
     with np.errstate(over="ignore"):
-        x = (np.asarray(idx).astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
-        x = x + np.uint64((int(seed) + int(site) * 0xD6E8FEB86659FD93) & m64)
-        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
-        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
-        x ^= x >> np.uint64(31)
+        x = lo * u32(0x9E3779B1) + hi * u32(0xC2B2AE35) + u32(const)
+        x ^= x >> u32(16); x *= u32(0x85EBCA6B)
+        x ^= x >> u32(13); x *= u32(0xC2B2AE35)
+        x ^= x >> u32(16)
     thresh = int(np.float32(p) * np.float32(16777216.0))
-    keep = (x >> np.uint64(40)).astype(np.int64) >= thresh
+    keep = (x >> u32(8)).astype(np.int64) >= thresh
     return np.where(keep, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
 
 

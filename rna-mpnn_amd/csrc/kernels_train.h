@@ -6,10 +6,10 @@ struct TRows { const int* ntot; int mul; int maxrows; };   // row count = *ntot 
 
 // Dropout of the training path (the reference: nn.Dropout(p) after every GELU, mpnn.py:140,150, feature.py:200,
 // functional.py:69,124,184, and on the attention probabilities, functional.py:109).  The keep decision of one element is a
-// pure function of (seed, site, element index): a 64-bit counter hash, restated by the CPU oracle, so that the HIP
+// pure function of (seed, site, element index): a 32-bit counter hash (murmur3 finaliser), restated by the CPU oracle, so that the HIP
 // forward / backward and the oracle's autograd see THE SAME mask.  element index = row * D + channel with rows in
 // the packed order (node row p, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
-struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // keep iff hash24 >= thresh (= p * 2^24); scale = 1/(1-p)
+struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // keep iff (hash32 >> 8) >= thresh (= p * 2^24); scale = 1/(1-p)
 static inline TDrop t_drop(float p, unsigned long long seed) {
     TDrop d;
     d.seed = seed;
@@ -29,8 +29,9 @@ bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* 
                 int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s);
 bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
                 int ldy, int beta, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s);
+// dbias (optional): += column sums of A, computed from the tiles the kernel stages anyway (the bias gradient of the same Linear)
 void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
-                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, hipStream_t s);
+                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, float* dbias, hipStream_t s);
 void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s);   // out += column sums
 void t_gelu_fwd(const TRows& rows, const float* x, float* y, int D, const TDrop& dr, unsigned site, hipStream_t s);   // y = drop(gelu(x))
 void t_gelu_bwd(const TRows& rows, const float* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site,

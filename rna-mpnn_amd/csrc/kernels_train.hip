@@ -15,14 +15,27 @@ __device__ __forceinline__ float gelu_d(float x) {     // d/dx [x Phi(x)] = Phi(
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ int nrows(const TRows& r) { return *r.ntot * r.mul; }
-// dropout multiplier of one element: 0 or 1/(1-p) (kernels_train.h: TDrop; restated by oracle dropout_mask)
+// dropout multiplier of one element: 0 or 1/(1-p) (kernels_train.h: TDrop; restated by the oracle's dropout_multiplier).
+// 32-bit counter hash (murmur3 finaliser) of (seed, site, 64-bit element index): ~12 integer instructions, no 64-bit multiply.
 __device__ __forceinline__ float drop_mul(const TDrop& d, unsigned site, unsigned long long idx) {
     if (d.thresh == 0u) return 1.f;
-    unsigned long long x = (idx + 1ull) * 0x9E3779B97F4A7C15ull + d.seed + (unsigned long long)site * 0xD6E8FEB86659FD93ull;
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (unsigned)(x >> 40) >= d.thresh ? d.scale : 0.f;
+    unsigned x = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0xC2B2AE35u + site * 0x85EBCA6Bu
+               + (unsigned)d.seed + (unsigned)(d.seed >> 32) * 0x27D4EB2Fu;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return (x >> 8) >= d.thresh ? d.scale : 0.f;
+}
+// GELU and its derivative for the fused prologues / epilogues of the bf16-mixed GEMMs: Phi(x) ~ sigmoid(x (c0 + c1 x^2)),
+// coefficients minimax-fitted to the erf form (max |x Phi - gelu| 2.7e-4, below the bf16 rounding of the operands these
+// values are converted to); derivative = Phi + x phi.  The f32 kernels (parity grade) keep erff.
+__device__ __forceinline__ float phi_fast(float x) {
+    const float p = fmaf(x * x, -0.10012571f, -2.3087657f);           // -log2(e) (c0 + c1 x^2)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
+__device__ __forceinline__ float gelu_fast(float x) { return x * phi_fast(x); }
+__device__ __forceinline__ float gelu_d_fast(float x) {
+    return fmaf(x * 0.3989422804f, __builtin_amdgcn_exp2f(x * x * -0.72134752f), phi_fast(x));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,7 +103,25 @@ __global__ void k_reduce_parts(const float* __restrict__ part, int nparts, size_
     for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];
     out[(size_t)(i / cols) * ld_out + (i % cols)] += s;
 }
-static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s) {
+// first level of a two-level reduction: group g sums its contiguous run of partials (ascending) into tmp[g][count]
+__global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size_t stride, int count, int per_group,
+                                float* __restrict__ tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (i >= count) return;
+    const int p0 = g * per_group, p1 = min(nparts, p0 + per_group);
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += part[(size_t)p * stride + i];
+    tmp[(size_t)g * count + i] = s;
+}
+// (the association order is a function of nparts alone: bit-reproducible.  tmp: 16 * count floats behind the partials)
+static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s,
+                         float* tmp = nullptr) {
+    if (tmp && nparts > 32) {
+        const int G = 16, per = (nparts + G - 1) / G;
+        hipLaunchKernelGGL(k_reduce_groups, dim3((count + 255) / 256, G), dim3(256), 0, s, part, nparts, stride, count, per, tmp);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out);
+        return;
+    }
     hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out);
 }
 
@@ -152,13 +183,13 @@ __global__ void __launch_bounds__(256) k_colsum(TRows rows, const float* __restr
     }
 }
 void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s) {
-    int nb = (int)(sc.floats / (size_t)M);
-    if (nb > 1024) nb = 1024;
+    int nb = (int)(sc.floats / (size_t)M) - 16;
+    if (nb > 512) nb = 512;
     int rpb = (rows.maxrows + nb - 1) / nb;
     if (rpb < 64) rpb = 64;
     nb = (rows.maxrows + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, rows, A, lda, M, sc.p, rpb);
-    reduce_parts(sc.p, nb, (size_t)M, M, M, out, M, s);
+    reduce_parts(sc.p, nb, (size_t)M, M, M, out, M, s, sc.p + (size_t)nb * M);
 }
 
 // element-wise over rows x D (contiguous, ld = D)
@@ -678,7 +709,7 @@ __device__ __forceinline__ tu32x4 frag_row(const float* __restrict__ src, int ld
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     if (act) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]) * drop_mul(dr, site, (unsigned long long)row * ld_idx + k0 + j);
+        for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * drop_mul(dr, site, (unsigned long long)row * ld_idx + k0 + j);
     }
     if (!ok) {
 #pragma unroll
@@ -695,7 +726,7 @@ __device__ __forceinline__ tu32x4 frag_col(const float* __restrict__ src, int ld
     for (int j = 0; j < 8; ++j) { const int kk = k0 + j; v[j] = src[(size_t)(kk < nk ? kk : 0) * ld + cc]; }
     if (act) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]) * drop_mul(dr, site, (unsigned long long)(k0 + j) * ld_idx + col);
+        for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * drop_mul(dr, site, (unsigned long long)(k0 + j) * ld_idx + col);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (k0 + j >= nk || col >= ncols) v[j] = 0.f;
@@ -747,7 +778,7 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
                 const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (colok && row < R) {
                     float v = acc[a][b][i] + bv;
-                    if (epi_pre) v *= gelu_d(epi_pre[(size_t)row * ld_epi + col]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
+                    if (epi_pre) v *= gelu_d_fast(epi_pre[(size_t)row * ld_epi + col]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
                     float* y = Y + (size_t)row * ldy + col;
                     *y = beta ? *y + v : v;
                 }
@@ -755,6 +786,107 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
         }
     }
 }
+// ---- NT / NN for the dominant shape K = N = 128 (the per-edge Linears): the whole weight lives in REGISTERS as 32 B
+// fragments (built once per workgroup through an LDS fragment image), a wave streams 32-row tiles of X past it:
+// 16 coalesced 16-byte loads and 32 MFMAs per tile, no LDS traffic in the loop.
+template <bool B_ROWS>
+__global__ void __launch_bounds__(256, 1) k_mm128(TRows rows, const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+        const float* __restrict__ bias, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
+        TDrop dr, unsigned site) {
+    __shared__ __attribute__((aligned(16))) unsigned short img[32 * 64 * 8];      // [ks][cb][lane][8] bf16
+    const int R = nrows(rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    // B[k][col] = B_ROWS ? W[col][k] : W[k][col]; two k-adjacent elements per 32-bit LDS write
+    for (int e = tid; e < 128 * 64; e += 256) {
+        int k, col;
+        float v0, v1;
+        if (B_ROWS) { col = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)col * ldw + k; v0 = p[0]; v1 = p[1]; }
+        else { k = 2 * (e >> 7); col = e & 127; v0 = W[(size_t)k * ldw + col]; v1 = W[(size_t)(k + 1) * ldw + col]; }
+        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = col >> 5, rr = col & 31;
+        *reinterpret_cast<unsigned*>(img + (((ks * 4 + cb) * 64 + hh * 32 + rr) * 8 + j)) = tpack2(v0, v1);
+    }
+    __syncthreads();
+    // one wave per SIMD with the whole 512-register file: 128 registers of weight fragments + a full tile of X in flight
+    tu32x4 bf[8][4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bf[ks][cb] = reinterpret_cast<const tu32x4*>(img)[(ks * 4 + cb) * 64 + lane];
+    float bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bv[cb] = bias ? bias[32 * cb + r] : 0.f;
+    const int ntiles = (R + 31) / 32;
+    const int tstride = gridDim.x * 4;
+    tf32x4 raw[16];
+    auto load_raw = [&](int t) {                              // this lane's row of tile t: 8 floats per k-step (rows clamped)
+        const int row = min(32 * t + r, R - 1);
+        const float* p = X + (size_t)row * ldx + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            raw[2 * ks] = *reinterpret_cast<const tf32x4*>(p + 16 * ks);
+            raw[2 * ks + 1] = *reinterpret_cast<const tf32x4*>(p + 16 * ks + 4);
+        }
+    };
+    int t = blockIdx.x * 4 + wave;
+    if (t < ntiles) load_raw(t);
+    for (; t < ntiles; t += tstride) {
+        const int row = 32 * t + r;
+        tu32x4 af[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float v[8] = {raw[2 * ks][0], raw[2 * ks][1], raw[2 * ks][2], raw[2 * ks][3],
+                          raw[2 * ks + 1][0], raw[2 * ks + 1][1], raw[2 * ks + 1][2], raw[2 * ks + 1][3]};
+            if (actA) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * drop_mul(dr, site, (unsigned long long)row * 128 + 16 * ks + 8 * h + j);
+            }
+            if (row >= R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            af[ks] = tpack8(v);
+        }
+        if (t + tstride < ntiles) load_raw(t + tstride);      // next tile's loads fly under this tile's MFMAs and stores
+        tf32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][i] = bv[cb];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(af[ks], bf[ks][cb], acc[cb]);
+        // epilogue: the loads of a column block (old Y for beta, the taped pre-activation for the GELU backward) go out as
+        // one batch with clamped rows - a load -> use -> store chain per element would expose one memory round trip each
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = 32 * cb + r;
+            float yo[16], pr[16];
+            if (beta) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) yo[i] = Y[(size_t)min(32 * t + (i & 3) + 8 * (i >> 2) + 4 * h, R - 1) * ldy + col];
+            }
+            if (epi_pre) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pr[i] = epi_pre[(size_t)min(32 * t + (i & 3) + 8 * (i >> 2) + 4 * h, R - 1) * 128 + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int orow = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[cb][i];
+                if (epi_pre) v *= gelu_d_fast(pr[i]) * drop_mul(dr, site, (unsigned long long)orow * 128 + col);
+                if (beta) v += yo[i];
+                if (orow < R) Y[(size_t)orow * ldy + col] = v;
+            }
+        }
+    }
+}
+static int mm128_grid(const TRows& rows) {
+    int g = (rows.maxrows + 127) / 128;                      // 4 waves x one 32-row tile each
+    const int cap = rn_num_cus();                            // one workgroup per CU (one wave per SIMD)
+    return g > cap ? cap : (g < 1 ? 1 : g);
+}
+
 static bool mm_ok(const void* X, int ldx, int K, const void* W, int ldw, bool b_rows) {
     return K % 16 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && (!b_rows || (ldw % 4 == 0 && ((uintptr_t)W & 15) == 0));
 }
@@ -762,6 +894,11 @@ static bool mm_ok(const void* X, int ldx, int K, const void* W, int ldw, bool b_
 bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
                 int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s) {
     if (!mm_ok(X, ldx, K, W, ldw, true)) return false;
+    if (K == 128 && N == 128 && ldw % 2 == 0) {
+        hipLaunchKernelGGL(k_mm128<true>, dim3(mm128_grid(rows)), dim3(256), 0, s, rows, X, ldx, W, ldw, bias, Y, ldy, beta,
+                           actA ? 1 : 0, (const float*)nullptr, dr, site);
+        return true;
+    }
     dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
     hipLaunchKernelGGL(k_mm<true>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0,
                        (const float*)nullptr, 0, dr, site);
@@ -771,63 +908,151 @@ bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* 
 bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
                 int ldy, int beta, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s) {
     if (!mm_ok(X, ldx, K, W, ldw, false)) return false;
+    if (K == 128 && N == 128 && (!epi_pre || ld_epi == 128)) {
+        hipLaunchKernelGGL(k_mm128<false>, dim3(mm128_grid(rows)), dim3(256), 0, s, rows, X, ldx, W, ldw, bias, Y, ldy, beta, 0,
+                           epi_pre, dr, site);
+        return true;
+    }
     dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
     hipLaunchKernelGGL(k_mm<false>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, 0, epi_pre, ld_epi, dr, site);
     return true;
 }
 
-// ---- TN: dW[n][kk] += sum_m A[m][n] * actB(B[m][kk]): contraction over ROWS; both fragments are column reads.
-// Workgroup = 4 waves on one 128 (n) x 128 (kk) output tile: wave = (kk half, row-slice parity); the row range is split
-// over blockIdx.z; every (split, parity) writes its own partial tile, k_reduce_parts adds them in order.
+// ---- TN: dW[n][kk] += sum_m A[m][n] * actB(B[m][kk]): contraction over ROWS.  Both operands are needed k-major (k = row
+// index) while the tensors are row-major: 64-row tiles are staged row-major in LDS as bf16 (coalesced 16-byte global loads,
+// 8-byte LDS writes) and read back TRANSPOSED by ds_read_b64_tr_b16 (a 4-row x 16-column block per 16-lane group, delivered
+// column-major: exactly the 32x32x16 operand).  Row pitch 320 B makes both the writes and the transposed reads conflict-free.
+// Workgroup = 4 waves on one 128 (n) x 128 (kk) output tile (wave = 64 x 64 quadrant); the row range is split over
+// blockIdx.z, every split writes its own partial tile, reduce_parts adds them in order.
+#define TN_PITCH 160                                          // bf16 elements per LDS row (128 data + 32 pad)
+typedef __attribute__((ext_vector_type(4))) short ts16x4;
+__device__ __forceinline__ tu32x4 tr_frag(const unsigned short* tile, int row0, int col0, int lane) {
+    const int g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3, h = lane >> 5;
+    const unsigned short* a = tile + (row0 + 8 * h + q) * TN_PITCH + col0 + 16 * g + 4 * p;
+    const ts16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ts16x4*)a);
+    const ts16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ts16x4*)(a + 4 * TN_PITCH));
+    typedef __attribute__((ext_vector_type(2))) unsigned tu32x2;
+    const tu32x2 l2 = __builtin_bit_cast(tu32x2, lo), h2 = __builtin_bit_cast(tu32x2, hi);
+    return tu32x4{l2[0], l2[1], h2[0], h2[1]};
+}
 __global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restrict__ A, int lda, int M, const float* __restrict__ B,
-        int ldb, int K, float* __restrict__ part, int rows_per_split, int actB, TDrop dr, unsigned site) {
+        int ldb, int K, float* __restrict__ part, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+    __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
+    __shared__ float cs_red[8][128];
     const int R = nrows(rows);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int half = wave & 1, par = wave >> 1;
-    const int n0 = blockIdx.x * 128, kk0 = blockIdx.y * 128 + 64 * half;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * 128, kk0 = blockIdx.y * 128;
     const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
-    tf32x16 acc[4][2];
+    // staging map: thread -> 8 (row, 4-column group) cells of the 64 x 128 tile; cg fastest: coalesced 512-B rows
+    const int cg = tid & 31, rg = tid >> 5;                   // columns 4cg .. 4cg+3; rows rg, rg+8, ...
+    tf32x4 ra[8], rb[8];
+    tf32x4 csum = {0.f, 0.f, 0.f, 0.f};                       // column sums of A over this thread's rows (bias gradient, optional)
+    auto load_tile = [&](int m0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + rg + 8 * i;
+            const bool ok = m < p_end;
+            const int mc = ok ? m : (R > 0 ? R - 1 : 0);
+            const int ca = n0 + 4 * cg, cb = kk0 + 4 * cg;
+            tf32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (ca + 3 < M) va = *reinterpret_cast<const tf32x4*>(A + (size_t)mc * lda + ca);
+            else for (int c = 0; c < 4; ++c) if (ca + c < M) va[c] = A[(size_t)mc * lda + ca + c];
+            if (cb + 3 < K) vb = *reinterpret_cast<const tf32x4*>(B + (size_t)mc * ldb + cb);
+            else for (int c = 0; c < 4; ++c) if (cb + c < K) vb[c] = B[(size_t)mc * ldb + cb + c];
+            if (actB) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vb[c] = gelu_fast(vb[c]) * drop_mul(dr, site, (unsigned long long)m * K + cb + c);
+            }
+            if (!ok) { va = tf32x4{0.f, 0.f, 0.f, 0.f}; vb = va; }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    auto store_tile = [&]() {
+        typedef __attribute__((ext_vector_type(2))) unsigned tu32x2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rg + 8 * i;
+            *reinterpret_cast<tu32x2*>(tA + row * TN_PITCH + 4 * cg) = tu32x2{tpack2(ra[i][0], ra[i][1]), tpack2(ra[i][2], ra[i][3])};
+            *reinterpret_cast<tu32x2*>(tB + row * TN_PITCH + 4 * cg) = tu32x2{tpack2(rb[i][0], rb[i][1]), tpack2(rb[i][2], rb[i][3])};
+        }
+    };
+    tf32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    for (int m0 = p_begin + 16 * par; m0 < p_end; m0 += 32) {
-        tu32x4 af[4], bf[2];
+    if (p_begin < p_end) load_tile(p_begin);
+    for (int m0 = p_begin; m0 < p_end; m0 += 64) {
+        __syncthreads();                                      // the previous tile's fragment reads are done
+        store_tile();
+        if (cs_part) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) af[a] = frag_col(A, lda, m0 + 8 * h, p_end, n0 + 32 * a + r, M, false, dr, 0u, 0);
+            for (int i = 0; i < 8; ++i) csum += ra[i];
+        }
+        __syncthreads();
+        if (m0 + 64 < p_end) load_tile(m0 + 64);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bf[b] = frag_col(B, ldb, m0 + 8 * h, p_end, kk0 + 32 * b + r, K, actB != 0, dr, site, K);
+        for (int ks = 0; ks < 4; ++ks) {
+            tu32x4 af[2], bf[2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(tA, 16 * ks, 64 * wr + 32 * a, lane);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(tB, 16 * ks, 64 * wc + 32 * b, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+        }
     }
-    float* dst = part + ((size_t)blockIdx.z * 2 + par) * M * K;
+    if (cs_part && blockIdx.y == 0) {                         // rows rg, rg+8, ... were summed per thread: fold the 8 row groups in order
+        *reinterpret_cast<tf32x4*>(&cs_red[rg][4 * cg]) = csum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < M) {
+            float t = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+            for (int g = 0; g < 8; ++g) t += cs_red[g][tid];
+            cs_part[(size_t)blockIdx.z * M + n0 + tid] = t;
+        }
+    }
+    float* dst = part + (size_t)blockIdx.z * M * K;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int col = kk0 + 32 * b + r;
+            const int col = kk0 + 64 * wc + 32 * b + r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = n0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int row = n0 + 64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (row < M && col < K) dst[(size_t)row * K + col] = acc[a][b][i];
             }
         }
 }
 void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
-                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, hipStream_t s) {
-    long long cap = (long long)(sc.floats / ((size_t)M * K)) / 2;
-    int splits = (rows.maxrows + 4095) / 4096;
-    if (splits > 256) splits = 256;
+                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
+    const size_t mk = (size_t)M * K;
+    const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
+    long long cap = (long long)((sc.floats - (size_t)520 * M) / mk) - 16;   // behind the partials: 16 * mk floats for the two-level reduction, 520 * M for the column sums
+    int splits = (rows.maxrows + 1023) / 1024;                // >= 1024 rows (16 tiles) per workgroup
+    const int want = (2 * rn_num_cus() + tiles - 1) / tiles;  // enough workgroups for the chip
+    if (splits > want) splits = want;
     if (splits > cap) splits = (int)cap;
+    if (splits > 500) splits = 500;
     if (splits < 1) splits = 1;
-    int rps = ((rows.maxrows + splits - 1) / splits + 31) / 32 * 32;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    if ((lda % 4) || (ldb % 4) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || actB && cap < 1) {     // 16-byte row loads need aligned rows
+        t_gemm_tn(rows, A, lda, M, B, ldb, K, dW, ldw, sc, s);
+        if (dbias) t_colsum(rows, A, lda, M, dbias, sc, s);
+        return;
+    }
+    float* tmp = sc.p + (size_t)splits * mk;                  // [16][mk] second-level buffer, then [splits + 16][M] column sums
+    float* cs = dbias ? tmp + 16 * mk : nullptr;
     dim3 grid((M + 127) / 128, (K + 127) / 128, splits);
-    hipLaunchKernelGGL(k_mm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, rps, actB ? 1 : 0, dr, site);
-    reduce_parts(sc.p, splits * 2, (size_t)M * K, M * K, K, dW, ldw, s);
+    hipLaunchKernelGGL(k_mm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, rps, actB ? 1 : 0, dr, site, cs);
+    reduce_parts(sc.p, splits, mk, (int)mk, K, dW, ldw, s, tmp);
+    if (dbias) reduce_parts(cs, splits, (size_t)M, M, M, dbias, M, s, cs + (size_t)splits * M);
 }
 
 // ------------------------------------------------------------------------------------------
