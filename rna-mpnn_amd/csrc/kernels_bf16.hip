@@ -1341,20 +1341,33 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
 // the edge kernel).
 __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
         const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ coef) {
-    __shared__ float4 rs[8][8], rq[8][8];
+    // TWO-PASS statistics (mean, then sum of squared deviations): the one-pass form sum x^2 + (T - 2n) mu^2 cancels once |h| >> sigma
+    __shared__ float4 red[4][8];
     const int b = blockIdx.x, cg = blockIdx.y;                 // RNA, group of 32 channels
     const int n = pk.len[b];
     if (n <= 0) return;
     const size_t base = (size_t)pk.cu[b] * RN_D + 32 * cg;
     const int cq = threadIdx.x & 7, g = threadIdx.x >> 3;      // channel quad, row group (32)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
     const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-    auto accum = [&](float4 v) {
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+    // reduce a per-thread float4 over the 32 row groups: 4 lanes-of-8 per wave via shuffles, then the 4 waves via LDS (fixed order)
+    auto block_sum = [&](float4 s) -> float4 {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        __syncthreads();                                       // red[] of a previous call has been consumed
+        if (lane < 8) red[wave][lane] = s;
+        __syncthreads();
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 u = red[w][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        return t;
     };
-    if (n <= 160) {         // all loads of the thread in flight together (rows clamped, contributions predicated)
+    const float fn = (float)n;
+    float4 S, Q;
+    if (n <= 160) {         // rows stay in registers between the two passes (all loads of the thread in flight together)
         float4 v[5], a[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) { const int r = g + 32 * i, rc = r < n ? r : n - 1; v[i] = xb[(size_t)rc * 32]; }
@@ -1364,40 +1377,46 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
 #pragma unroll
             for (int i = 0; i < 5; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
         }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) if (g + 32 * i < n) accum(v[i]);
+        for (int i = 0; i < 5; ++i) if (g + 32 * i < n) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        S = block_sum(s);
+        const float4 mu = make_float4(S.x / fn, S.y / fn, S.z / fn, S.w / fn);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (g + 32 * i < n) {
+            const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+        }
+        Q = block_sum(q);
     } else {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = g; r < n; r += 32) {
             float4 v = xb[(size_t)r * 32];
-            if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-            accum(v);
+            if (ab) { const float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+        S = block_sum(s);
+        const float4 mu = make_float4(S.x / fn, S.y / fn, S.z / fn, S.w / fn);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = g; r < n; r += 32) {
+            float4 v = xb[(size_t)r * 32];
+            if (ab) { const float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+        }
+        Q = block_sum(q);
     }
-    // reduce the 32 row groups: 4 lanes-of-8 per wave via shuffles, then 4 waves via LDS
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
-        q.x += __shfl_xor(q.x, o, 64); q.y += __shfl_xor(q.y, o, 64); q.z += __shfl_xor(q.z, o, 64); q.w += __shfl_xor(q.w, o, 64);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < 8) { rs[wave][lane] = s; rq[wave][lane] = q; }
-    __syncthreads();
     if (threadIdx.x < 8) {
-        float4 S = rs[0][cq], Q = rq[0][cq];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            float4 u = rs[w][cq], v = rq[w][cq];
-            S.x += u.x; S.y += u.y; S.z += u.z; S.w += u.w; Q.x += v.x; Q.y += v.y; Q.z += v.z; Q.w += v.w;
-        }
-        const float fn = (float)n, pad = (float)(t_tot - 2 * n);
+        const float pad = (float)(t_tot - n);
         const float4 sc = reinterpret_cast<const float4*>(scale + 32 * cg)[cq], sh = reinterpret_cast<const float4*>(shift + 32 * cg)[cq];
-        float mean[4] = {S.x / fn, S.y / fn, S.z / fn, S.w / fn};
-        float sq[4] = {Q.x, Q.y, Q.z, Q.w}, scl[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float mean[4] = {S.x / fn, S.y / fn, S.z / fn, S.w / fn};
+        const float sq[4] = {Q.x, Q.y, Q.z, Q.w}, scl[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
         float a[4], bb[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // var = [sum (x-mu)^2 + (T-n) mu^2] / n = [sum x^2 + (T - 2n) mu^2] / n
-            float var = fmaxf((sq[i] + pad * mean[i] * mean[i]) / fn, 0.f);
+            // var = [sum_valid (x - mu)^2 + (T - n) mu^2] / n : padded rows enter as (0 - mu)^2 (functional.py:33-38)
+            const float var = (sq[i] + pad * mean[i] * mean[i]) / fn;
             a[i] = scl[i] / sqrtf(var + kSEPS);
             bb[i] = shf[i] - mean[i] * a[i];
         }
@@ -1533,108 +1552,120 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
 
 // ------------------------------------------------------------------------------------------
 // nn.MultiheadAttention over the valid keys of one RNA on MFMA (functional.py:164-168), head dim 16.
-// One workgroup per (RNA, head); wave w owns queries 32w .. 32w+31 of a 256-query sweep.
+// One workgroup per (RNA, head, 256-query slab); wave w owns queries 32w .. 32w+31 of the slab.
 // Transposed like everything else here: S^T[key][query] = K . Q^T puts ONE query on each lane and the
 // keys of a 32-key block on the accumulator registers, so the online softmax is in-lane (+ one
 // cross-half exchange), and the P tile is, as it stands, the B operand of O^T[d][query] += V^T . P.
-// K rows and the (k-permuted) V^T image of the whole RNA sit in LDS as ready fragments.
-__global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const float* __restrict__ qkv, float* __restrict__ out) {
+// K rows and the (k-permuted) V^T image sit in LDS as ready fragments, staged in CHUNKS of at most `chunk_blocks`
+// 32-key blocks (2 KiB each): any RNA length runs through the same kernel (the reference pads to 4,500,
+// functional.py:153-159); the softmax state of a wave's one query tile lives in registers across the chunks.
+__global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const float* __restrict__ qkv, float* __restrict__ out,
+                                                             int chunk_blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, hd = blockIdx.y;
     const int n = pk.len[b];
-    if (n <= 0) return;
+    const int qbase = blockIdx.z * 256;
+    if (n <= 0 || qbase >= n) return;                          // (whole workgroup: uniform)
     const int base = pk.cu[b];
     const int nkb = (n + 31) / 32;
+    const int chb = min(chunk_blocks, nkb);
     u32x4* Kimg = reinterpret_cast<u32x4*>(smem);              // [key][2 halves] : 8 bf16 each
-    u32x4* Vt = Kimg + (size_t)nkb * 64;                       // [kb][s][h][d 0..15] : 8 permuted keys each
+    u32x4* Vt = Kimg + (size_t)chb * 64;                       // [kb][s][h][d 0..15] : 8 permuted keys each
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < nkb * 64; idx += 512) {          // K rows
-        const int key = idx >> 1, hh = idx & 1;
-        // (rows clamped and the result masked: a conditional load per element would serialise into one memory round trip each)
-        const float* kp = qkv + (size_t)(base + (key < n ? key : n - 1)) * 384 + 128 + hd * 16 + 8 * hh;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(kp), c = *reinterpret_cast<const f32x4*>(kp + 4);
-        const u32x4 v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
-        Kimg[idx] = key < n ? v : u32x4{0u, 0u, 0u, 0u};
-    }
-    for (int idx = tid; idx < nkb * 64; idx += 512) {          // V^T fragments
-        const int d = idx & 15, hh = (idx >> 4) & 1, sblk = (idx >> 5) & 1, kb = idx >> 6;
-        float vals[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
-            vals[j] = qkv[(size_t)(base + (key < n ? key : n - 1)) * 384 + 256 + hd * 16 + d];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
-            if (key >= n) vals[j] = 0.f;
-        }
-        Vt[idx] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
-    }
-    __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int q0 = 32 * wave; q0 < n; q0 += 256) {
-        const int qi = q0 + r;
-        u32x4 qf = zero4;
-        if (qi < n) {
-            const float* qp = qkv + (size_t)(base + qi) * 384 + hd * 16 + 8 * h;
-            f32x4 a = *reinterpret_cast<const f32x4*>(qp), c = *reinterpret_cast<const f32x4*>(qp + 4);
-            qf = u32x4{pack2(0.25f * a[0], 0.25f * a[1]), pack2(0.25f * a[2], 0.25f * a[3]),
-                       pack2(0.25f * c[0], 0.25f * c[1]), pack2(0.25f * c[2], 0.25f * c[3])};
+    const int q0 = qbase + 32 * wave;
+    const bool wave_live = q0 < n;                             // wave-uniform; dead waves still stage and hit the barriers
+    const int qi = q0 + r;
+    u32x4 qf = zero4;
+    if (qi < n) {
+        const float* qp = qkv + (size_t)(base + qi) * 384 + hd * 16 + 8 * h;
+        f32x4 a = *reinterpret_cast<const f32x4*>(qp), c = *reinterpret_cast<const f32x4*>(qp + 4);
+        qf = u32x4{pack2(0.25f * a[0], 0.25f * a[1]), pack2(0.25f * a[2], 0.25f * a[3]),
+                   pack2(0.25f * c[0], 0.25f * c[1]), pack2(0.25f * c[2], 0.25f * c[3])};
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float m_run = -3.0e38f, l_run = 0.f;
+    for (int kb0 = 0; kb0 < nkb; kb0 += chb) {
+        const int cb = min(chb, nkb - kb0);                    // blocks in this chunk
+        if (kb0 > 0) __syncthreads();                          // the previous chunk has been consumed
+        for (int idx = tid; idx < cb * 64; idx += 512) {       // K rows
+            const int key = 32 * kb0 + (idx >> 1), hh = idx & 1;
+            // (rows clamped and the result masked: a conditional load per element would serialise into one memory round trip each)
+            const float* kp = qkv + (size_t)(base + (key < n ? key : n - 1)) * 384 + 128 + hd * 16 + 8 * hh;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kp), c = *reinterpret_cast<const f32x4*>(kp + 4);
+            const u32x4 v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
+            Kimg[idx] = key < n ? v : zero4;
         }
-        f32x16 acc;
+        for (int idx = tid; idx < cb * 64; idx += 512) {       // V^T fragments
+            const int d = idx & 15, hh = (idx >> 4) & 1, sblk = (idx >> 5) & 1, kb = kb0 + (idx >> 6);
+            float vals[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float m_run = -3.0e38f, l_run = 0.f;
-        for (int kb = 0; kb < nkb; ++kb) {
-            f32x16 sc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
-            sc = mfma32(Kimg[(32 * kb + r) * 2 + h], qf, sc);                  // S^T[key][query]
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                sc[i] = key < n ? sc[i] : -3.0e38f;
-                mx = fmaxf(mx, sc[i]);
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+                vals[j] = qkv[(size_t)(base + (key < n ? key : n - 1)) * 384 + 256 + hd * 16 + d];
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float corr = __expf(m_run - m_new);
-            float ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
-            l_run = l_run * corr + ps;
-            m_run = m_new;
+            for (int j = 0; j < 8; ++j) {
+                const int key = 32 * kb + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+                if (key >= n) vals[j] = 0.f;
+            }
+            Vt[idx] = u32x4{pack2(vals[0], vals[1]), pack2(vals[2], vals[3]), pack2(vals[4], vals[5]), pack2(vals[6], vals[7])};
+        }
+        __syncthreads();
+        if (wave_live) {
+            for (int kl = 0; kl < cb; ++kl) {
+                const int kb = kb0 + kl;
+                f32x16 sc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] *= corr;
+                for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+                sc = mfma32(Kimg[(32 * kl + r) * 2 + h], qf, sc);                  // S^T[key][query]
+                float mx = -3.0e38f;
 #pragma unroll
-            for (int sblk = 0; sblk < 2; ++sblk) {
-                const u32x4 pf = {pack2(sc[8 * sblk], sc[8 * sblk + 1]), pack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
-                                  pack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), pack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
-                const u32x4 vf = r < 16 ? Vt[((kb * 2 + sblk) * 2 + h) * 16 + r] : zero4;
-                acc = mfma32(vf, pf, acc);                                       // O^T[d][query]
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sc[i] = key < n ? sc[i] : -3.0e38f;
+                    mx = fmaxf(mx, sc[i]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run, mx);
+                const float corr = __expf(m_run - m_new);
+                float ps = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
+                l_run = l_run * corr + ps;
+                m_run = m_new;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] *= corr;
+#pragma unroll
+                for (int sblk = 0; sblk < 2; ++sblk) {
+                    const u32x4 pf = {pack2(sc[8 * sblk], sc[8 * sblk + 1]), pack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                      pack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), pack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                    const u32x4 vf = r < 16 ? Vt[((kl * 2 + sblk) * 2 + h) * 16 + r] : zero4;
+                    acc = mfma32(vf, pf, acc);                                   // O^T[d][query]
+                }
             }
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (qi < n) {
-            const float inv = 1.0f / l_tot;
-            float* op = out + (size_t)(base + qi) * RN_D + hd * 16 + 4 * h;      // rows d = (i&3) + 8(i>>2) + 4h, i < 8
-            *reinterpret_cast<f32x4*>(op) = f32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
-            *reinterpret_cast<f32x4*>(op + 8) = f32x4{acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
-        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qi < n) {
+        const float inv = 1.0f / l_tot;
+        float* op = out + (size_t)(base + qi) * RN_D + hd * 16 + 4 * h;      // rows d = (i&3) + 8(i>>2) + 4h, i < 8
+        *reinterpret_cast<f32x4*>(op) = f32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+        *reinterpret_cast<f32x4*>(op + 8) = f32x4{acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
     }
 }
 
-// returns 0 when handled (head dim 16 and the RNA's K / V^T images fit LDS), 1 otherwise
+// returns 0 when handled (head dim 16), 1 otherwise (the caller uses the f32 kernel)
 int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float* out, hipStream_t s) {
     if (RN_D / heads != 16) return 1;
     const int nkb = (pk.T + 31) / 32;
-    const size_t lds = (size_t)nkb * 64 * 16 * 2;
-    if (lds > 150 * 1024) return 1;
+    const int chunk = nkb < 64 ? nkb : 64;                    // <= 128 KiB of K / V^T fragments per chunk
+    const size_t lds = (size_t)chunk * 64 * 16 * 2;
     static DevAttr attr;
     ensure_dyn_lds((const void*)k_attention_bf16_hd16, lds, attr);
-    hipLaunchKernelGGL(k_attention_bf16_hd16, dim3(pk.B, heads), dim3(512), lds, s, pk, qkv, out);
+    hipLaunchKernelGGL(k_attention_bf16_hd16, dim3(pk.B, heads, (pk.T + 255) / 256), dim3(512), lds, s, pk, qkv, out, chunk);
     return 0;
 }

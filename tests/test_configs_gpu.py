@@ -243,3 +243,25 @@ def test_packed_loader_forward_matches_oracle(c3_dir, precision):
         model.forward_packed(torch.zeros(10, 7, 3), torch.tensor([0, 4, 3, 10], dtype=torch.int32), 8)
     with pytest.raises(ValueError):
         model.forward_packed(torch.zeros(10, 7, 3), torch.tensor([0, 9, 10], dtype=torch.int32), 8)
+
+
+# ----------------------------------------------------------------------------------------------- longest RNA of the data set
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_longest_length_of_the_reference_data_4417_nt(precision):
+    """F4 (long-RNA half): the longest RNA of data/train_data.csv has 4,417 nt and the reference pads attention to 4,500
+    (functional.py:153-159).  A synthetic 4,417-nt backbone batched with a 50-nt one (T = 4,417, P = 4,500): k-NN with
+    the 64-lane LDS row, attention in key chunks of 2,048 (three chunks), GraphNorm with T_tot = T and P - against the
+    oracle run on the long RNA alone (same T, so the same normalisation)."""
+    from rnampnn.utils import synth
+    n = 4417
+    coords, mask, _ = synth.synth_batch([n, 50], first_index=7000)
+    hp = _hp(num_res_neighbours=30, padding_len=4500, num_res_mpnn_layers=4)
+    model, sd = _model(hp, precision)
+    lg = model(torch.from_numpy(coords), torch.from_numpy(mask)).cpu()
+    assert torch.isfinite(lg).all() and (lg[1, 50:] == 0).all()
+    ref = _oracle(hp, sd, coords[:1], mask[:1])
+    err = float((lg[:1] - ref).abs().max())
+    assert err < (1e-4 if precision == "f32" else bf16_tol(ref, mask[:1])), err
+    with pytest.raises(RuntimeError):                      # beyond padding_len: the reference's negative-size error (functional.py:155)
+        big_c, big_m, _ = synth.synth_batch([4501], first_index=1)
+        model(torch.from_numpy(big_c), torch.from_numpy(big_m))
