@@ -5,6 +5,7 @@
 #include "kernels_bf16.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -101,7 +102,26 @@ struct rnampnn_ctx {
     const void* tape_ws = nullptr;
     bool tape_mixed = false;
     bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
+    // fork / join inside one forward: independent branches of the node stack run on auxiliary streams beside the
+    // latency-bound kernels of the caller's stream (k-NN at the start, the small attention kernels at the end)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t fj[4] = {nullptr, nullptr, nullptr, nullptr};
+    int overlap = -1;              // -1: not decided yet.  OFF unless RNAMPNN_OVERLAP=1: measured null on C2 (2.602 vs 2.607 ms/step) -
+                                   // the branches cannot co-reside: k_ffn_chain needs 135 KiB of a CU's LDS, which the
+                                   // 5 resident k-NN workgroups (53 KiB) or a GEMM workgroup (36 KiB) do not leave free
 };
+
+static bool overlap_ready(rnampnn_ctx* c) {
+    if (c->overlap < 0) {
+        const char* e = getenv("RNAMPNN_OVERLAP");
+        c->overlap = (e && e[0] == '1') ? 1 : 0;
+        if (c->overlap) {
+            for (auto& a : c->aux) if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) c->overlap = 0;
+            for (auto& ev : c->fj) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) c->overlap = 0;
+        }
+    }
+    return c->overlap == 1;
+}
 
 static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {
     RawT t{key, numel, c->raw_floats, false};
@@ -304,6 +324,8 @@ extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t
 extern "C" int rnampnn_destroy(rnampnn_handle h) {
     if (!h) return RNAMPNN_OK;
     for (auto& e : h->ev) (void)hipEventDestroy(e);
+    for (auto& a : h->aux) if (a) (void)hipStreamDestroy(a);
+    for (auto& e : h->fj) if (e) (void)hipEventDestroy(e);
     if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
     if (h->der_arena) (void)hipFree(h->der_arena);
     delete h;
@@ -434,7 +456,7 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
 // ------------------------------------------------------------------------------------------
 struct Ws {                       // workspace carve (all offsets 256-byte aligned)
     int *len, *cu, *node_b, *nbr;
-    float *geom, *geomh, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
+    float *geom, *geomh, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *rb0, *rb1, *logits_p;
     float* coef;                  // fast path: per-RNA GraphNorm affine coefficients [B][256]
     bf16_t *q_e, *q_m;            // fast path: bf16 Q tables [(Nmax+1)][128]; pq_* then hold P as [(Nmax+1)][128] f32
     void* e;                      // f32 or bf16 [Nmax*k][128]
@@ -468,6 +490,8 @@ static size_t carve(const rnampnn_ctx* c, int B, size_t Nmax, char* base, Ws* w)
     r.n0 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n1 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n2 = (float*)take(Nmax * RN_D * sizeof(float));
+    r.rb0 = (float*)take(Nmax * RN_D * sizeof(float));        // raw-embedding branch (runs beside the post-fusion stack)
+    r.rb1 = (float*)take(Nmax * RN_D * sizeof(float));
     r.logits_p = (float*)take(Nmax * 4 * sizeof(float));
     r.e = (void*)take(c->cfg.precision == RNAMPNN_PREC_BF16 ? efrag_bytes((int)Nmax, (int)k) : Nmax * k * RN_D * esz);
     r.big = (float*)take(Nmax * k * RN_D * sizeof(float));
@@ -691,8 +715,29 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
 
     // ---- ResFeature.forward (feature.py:588-592)
     launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, r.fast ? w.geomh : nullptr, s);
-    if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s))
+    const bool ovl = overlap_ready(c);
+    const bool fused_first = r.fast && io->stop_after != 1;
+    // fork: the node-embedding branch (raw_project -> RNABert -> GraphNorm [-> P|Q of layer 1]) needs only k_geom's output; it
+    // runs on an auxiliary stream beside the latency-bound k-NN kernel (disjoint workspace buffers) and joins before layer 1
+    if (ovl) { (void)hipEventRecord(c->fj[0], s); (void)hipStreamWaitEvent(c->aux[0], c->fj[0], 0); r.s = c->aux[0]; }
+    gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
+    rc = run_bert(r, c->emb, w.n0, w.n1);
+    if (!rc) {
+        if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass
+            launch_node_update(r.pk, w.n1, nullptr, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, w.coef, w.hA, 1,
+                               derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_b), w.pq_m, w.q_m,
+                               nullptr, nullptr, nullptr, nullptr, r.s);
+        else
+            launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, r.s);
+    }
+    if (ovl) { (void)hipEventRecord(c->fj[1], c->aux[0]); r.s = s; }
+    auto join0 = [&]() { if (ovl) (void)hipStreamWaitEvent(s, c->fj[1], 0); };
+    if (rc) { join0(); return rc; }
+    // edge branch on the caller's stream
+    if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s)) {
+        join0();
         return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
+    }
     if (r.fast)
         launch_edge_embed_bf16(r.pk, k, w.geomh, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
                                derp<float>(c, c->edge_embed_b1p), (bf16_t*)w.e, s);
@@ -701,16 +746,7 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
                               g.depth_res_edge_feature > 1 ? derp<float>(c, c->edge_embed[1].wt) : nullptr,
                               g.depth_res_edge_feature > 1 ? rawp(c, c->edge_embed[1].b) : nullptr,
                               g.depth_res_edge_feature, (float*)w.e, s);
-    gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
-    rc = run_bert(r, c->emb, w.n0, w.n1);
-    if (rc) return rc;
-    const bool fused_first = r.fast && io->stop_after != 1;
-    if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass
-        launch_node_update(r.pk, w.n1, nullptr, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, w.coef, w.hA, 1,
-                           derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_b), w.pq_m, w.q_m,
-                           nullptr, nullptr, nullptr, nullptr, s);
-    else
-        launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, s);
+    join0();
     if (io->h0) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h0, s);
     if (io->e0) unpack_e(r, io->e0);
     if (io->stop_after == 1) { HIP_TRY(hipGetLastError()); return RNAMPNN_OK; }
@@ -749,26 +785,41 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
             }
         }
     }
-    // ---- post fusion, raw embedding, readout (rnampnn.py:179-181)
+    // ---- post fusion, raw embedding, readout (rnampnn.py:179-181).  The raw-embedding branch (RawFFN + GraphNorm) depends on
+    // the raw features only: with the fused FFN kernel it runs on the second auxiliary stream beside the small kernels of the
+    // post-fusion attention stack (own output buffers rb0 / rb1) and joins before the read-out
+    const bool ovl_raw = ovl && r.fast && c->raw_chain.ok;
+    float* raw_emb = ovl_raw ? w.rb1 : w.n2;
+    if (ovl_raw) {
+        (void)hipEventRecord(c->fj[2], s); (void)hipStreamWaitEvent(c->aux[1], c->fj[2], 0);
+        r.s = c->aux[1];
+        run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.rb0);
+        launch_graph_norm_packed(r.pk, w.rb0, nullptr, w.rb1, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, r.s);
+        (void)hipEventRecord(c->fj[3], c->aux[1]);
+        r.s = s;
+    }
     rc = run_bert(r, c->post, w.hA, w.n0);                     // h_post -> n0
+    if (ovl_raw) (void)hipStreamWaitEvent(s, c->fj[3], 0);
     if (rc) return rc;
-    run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
-    launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
+    if (!ovl_raw) {
+        run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
+        launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
+    }
     if (io->h_post) launch_unpack_nodes(r.pk, w.n0, RN_D, RN_D, io->h_post, s);
-    if (io->raw_emb) launch_unpack_nodes(r.pk, w.n2, RN_D, RN_D, io->raw_emb, s);
+    if (io->raw_emb) launch_unpack_nodes(r.pk, raw_emb, RN_D, RN_D, io->raw_emb, s);
     if (io->embedding) {
         launch_unpack_nodes_strided(r.pk, w.n0, RN_D, RN_D, io->embedding, 2 * RN_D, 0, s);
-        launch_unpack_nodes_strided(r.pk, w.n2, RN_D, RN_D, io->embedding, 2 * RN_D, RN_D, s);
+        launch_unpack_nodes_strided(r.pk, raw_emb, RN_D, RN_D, io->embedding, 2 * RN_D, RN_D, s);
     }
     if (po && po->embedding) {      // packed rows: cat(h_post, raw_emb) by two strided copies
         HIP_TRY(hipMemcpy2DAsync(po->embedding, 2 * RN_D * sizeof(float), w.n0, RN_D * sizeof(float), RN_D * sizeof(float),
                                  po->n_total, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpy2DAsync(po->embedding + RN_D, 2 * RN_D * sizeof(float), w.n2, RN_D * sizeof(float),
+        HIP_TRY(hipMemcpy2DAsync(po->embedding + RN_D, 2 * RN_D * sizeof(float), raw_emb, RN_D * sizeof(float),
                                  RN_D * sizeof(float), po->n_total, hipMemcpyDeviceToDevice, s));
     }
     const bool want_logits = io->logits || (po && po->logits);
     float* logits_rows = (po && po->logits) ? po->logits : w.logits_p;      // packed output is written in place
-    if (want_logits && run_chain(r, c->readout_chain, c->readout, w.n0, RN_D, w.n2, RN_D, logits_rows, 4)) {
+    if (want_logits && run_chain(r, c->readout_chain, c->readout, w.n0, RN_D, raw_emb, RN_D, logits_rows, 4)) {
         if (io->logits) launch_unpack_nodes(r.pk, logits_rows, 4, 4, io->logits, s);
     } else if (want_logits) {
         const float* cur = nullptr;
@@ -778,7 +829,7 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
             const Lin& l = c->readout[i];
             bool last = i + 1 == c->readout.size();
             float* dst = last ? logits_rows : bufs[i & 1];
-            if (i == 0) gemm(r, l, w.n0, RN_D, dst, l.out, nullptr, 0, w.n2, RN_D, RN_D);   // cat(h_post, raw_emb)
+            if (i == 0) gemm(r, l, w.n0, RN_D, dst, l.out, nullptr, 0, raw_emb, RN_D, RN_D);   // cat(h_post, raw_emb)
             else gemm(r, l, cur, ld, dst, l.out);
             cur = dst; ld = l.out;
         }
