@@ -237,7 +237,7 @@ def main():
         measured_cfg = args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch and world == 1
         traffic = None                  # HBM bytes per launch from PMC counters, when a profile of this workload is committed
         try:
-            prof = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            prof = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
             if measured_cfg:
                 traffic = prof["traffic_bytes_per_launch"]
         except Exception:
@@ -252,7 +252,7 @@ def main():
                 "launch_ms": launch_ms, "launches_timed": launches,
                 "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt, "nucleotides_per_launch": nt_call}
         if measured_cfg:    # these notes were measured on exactly this configuration (profiles/)
-            roof["traffic_note"] = "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_traffic.json"
+            roof["traffic_note"] = "bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/r02_pmc_traffic.json"
             roof["limiter"] = ("power: shader clock 1.84 GHz of 2.4 under MFMA + HBM/L2/LDS traffic; cycle count set by vector issue "
                                "(matrix pipe 47 %, vector issue 54 %, TA 68 % busy) - profiles/r01_pmc_k_mpnn_bf16_v3.txt, DESIGN.md section 4")
         out = {

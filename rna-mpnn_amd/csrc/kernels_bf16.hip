@@ -139,16 +139,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // first LDS write (a plain copy loop compiles to load -> wait -> write per iteration, i.e. one L2 round trip each).
 template <int NT>
 __device__ __forceinline__ void stage_image(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
-    constexpr int PER = 4096 / NT;
-    static_assert(4096 % NT == 0, "image size must be a multiple of the thread count");
+    constexpr int PER = (4096 + NT - 1) / NT;
     constexpr int BATCH = PER < 8 ? PER : 8;
+    constexpr bool EXACT = 4096 % NT == 0;
 #pragma unroll
     for (int b0 = 0; b0 < PER; b0 += BATCH) {
         u32x4 t[BATCH];
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) t[i] = src[tid + (b0 + i) * NT];
+        for (int i = 0; i < BATCH; ++i) if (b0 + i < PER) t[i] = src[EXACT ? tid + (b0 + i) * NT : min(tid + (b0 + i) * NT, 4095)];
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) dst[tid + (b0 + i) * NT] = t[i];
+        for (int i = 0; i < BATCH; ++i) if (b0 + i < PER && (EXACT || tid + (b0 + i) * NT < 4096)) dst[tid + (b0 + i) * NT] = t[i];
     }
 }
 // x as a (hi, lo) pair of bf16 in one word (hi in the low half): x = hi + lo to ~16 bits.  Operand of the k = 2 MFMAs that
