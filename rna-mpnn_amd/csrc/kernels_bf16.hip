@@ -19,6 +19,7 @@
 // ds_read_b128); a 512-thread workgroup per CU loads them once and then walks 32-edge blocks.
 #include "kernels_bf16.h"
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -1524,6 +1525,169 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     }
 }
 
+// The same update with ONE workgroup per RNA (n <= 256): GraphNorm statistics (two-pass), normalisation and the projections in one launch -
+// no k_gn_coef launch, no coefficient round trip through HBM.  The rows are read three times (two statistics passes in a
+// (channel quad, row group) mapping, then the MFMA mapping), the second and third time from L2.
+template <int NJOBS>
+__global__ void __launch_bounds__(256, 1) k_node_rna(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ h_out, PqJob j0, PqJob j1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* img = reinterpret_cast<u32x4*>(smem);
+    float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);          // [NJOBS][128]
+    float* lds_coef = lds_bias + 256;                                           // a[128] | b[128]
+    float4* red = reinterpret_cast<float4*>(lds_coef + 256);                    // [4 waves][32 quads]
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const int base = pk.cu[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    {   // ---- statistics: thread = (channel quad cq, row group g): rows g, g+8, ...
+        const int cq = tid & 31, g = tid >> 5;
+        const float4* xb = reinterpret_cast<const float4*>(x + (size_t)base * RN_D) + cq;
+        const float4* ab = add ? reinterpret_cast<const float4*>(add + (size_t)base * RN_D) + cq : nullptr;
+        auto block_sum = [&](float4 s) -> float4 {                  // over the 8 row groups, fixed order
+            s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64); s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
+            __syncthreads();
+            if (lane < 32) red[wave * 32 + lane] = s;
+            __syncthreads();
+            float4 t = red[cq];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const float4 u = red[w * 32 + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            return t;
+        };
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r0 = g; r0 < n; r0 += 64) {                        // 8 rows per thread in flight
+            float4 v[8], a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); v[i] = xb[(size_t)rw * 32]; }
+            if (ab) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); a[i] = ab[(size_t)rw * 32]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (r0 + 8 * i < n) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        }
+        const float4 S = block_sum(s);
+        const float fn = (float)n;
+        const float4 mu = make_float4(S.x / fn, S.y / fn, S.z / fn, S.w / fn);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r0 = g; r0 < n; r0 += 64) {
+            float4 v[8], a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); v[i] = xb[(size_t)rw * 32]; }
+            if (ab) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); a[i] = ab[(size_t)rw * 32]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (r0 + 8 * i < n) {
+                const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+            }
+        }
+        const float4 Q = block_sum(q);
+        if (g == 0) {
+            const float pad = (float)(t_tot - n);
+            const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+            const float mean[4] = {mu.x, mu.y, mu.z, mu.w}, sq[4] = {Q.x, Q.y, Q.z, Q.w};
+            const float scl[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // var = [sum_valid (x - mu)^2 + (T - n) mu^2] / n : padded rows enter as (0 - mu)^2 (functional.py:33-38)
+                const float var = (sq[i] + pad * mean[i] * mean[i]) / fn;
+                const float av = scl[i] / sqrtf(var + kSEPS);
+                lds_coef[4 * cq + i] = av;
+                lds_coef[128 + 4 * cq + i] = shf[i] - mean[i] * av;
+            }
+        }
+    }
+    // ---- normalise + project, 128 rows of the RNA at a time (one 32-row block per wave)
+    for (int blk0 = 0; blk0 < n; blk0 += 128) {
+        const int rl = blk0 + 32 * wave + r;
+        const bool ok = rl < n;
+        const size_t row = (size_t)base + (ok ? rl : n - 1);
+        f32x4 vx[8][2], va[8][2];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            vx[s][0] = *reinterpret_cast<const f32x4*>(x + row * RN_D + c0);
+            vx[s][1] = *reinterpret_cast<const f32x4*>(x + row * RN_D + c0 + 4);
+            if (add) {
+                va[s][0] = *reinterpret_cast<const f32x4*>(add + row * RN_D + c0);
+                va[s][1] = *reinterpret_cast<const f32x4*>(add + row * RN_D + c0 + 4);
+            }
+        }
+        if (blk0 == 0) {        // weight images and biases -> LDS while the row loads fly
+            __builtin_amdgcn_sched_barrier(0);
+            stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
+            if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
+            if (tid < 128) lds_bias[tid] = j0.bias[tid];
+            else if (NJOBS > 1) lds_bias[tid] = j1.bias[tid - 128];
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                         // images, biases and the coefficients are visible
+        }
+        if (add) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { vx[s][0] += va[s][0]; vx[s][1] += va[s][1]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            const f32x4 ca0 = *reinterpret_cast<const f32x4*>(lds_coef + c0), ca1 = *reinterpret_cast<const f32x4*>(lds_coef + c0 + 4);
+            const f32x4 cb0 = *reinterpret_cast<const f32x4*>(lds_coef + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(lds_coef + 128 + c0 + 4);
+            vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
+        }
+        u32x4 xf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 v0 = vx[s][0], v1 = vx[s][1];
+            xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+        }
+        if (ok && h_out) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int c0 = 16 * s + 8 * h;
+                *reinterpret_cast<f32x4*>(h_out + row * RN_D + c0) = vx[s][0];
+                *reinterpret_cast<f32x4*>(h_out + row * RN_D + c0 + 4) = vx[s][1];
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < NJOBS; ++jb) {
+            const PqJob& jbq = jb == 0 ? j0 : j1;
+            const u32x4* im = img + jb * 4096;
+#pragma unroll
+            for (int ob = 0; ob < 8; ++ob) {
+                f32x16 acc;
+                if (ob < 4) acc = init_vec16(lds_bias + jb * 128 + 32 * ob + 16 * h);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
+                if (ok) {
+                    if (ob < 4) {
+                        unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + row * RN_D + 32 * ob + 4 * h;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
+                                                                            split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
+                    } else {
+                        u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + row * RN_D + 32 * (ob - 4) + 16 * h);
+                        dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
+                        dst[1] = u32x4{pack2(acc[8], acc[9]), pack2(acc[10], acc[11]), pack2(acc[12], acc[13]), pack2(acc[14], acc[15])};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 // [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256]
 __global__ void k_build_pq_image(const float* __restrict__ w0, bf16_t* __restrict__ dst) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1539,8 +1703,20 @@ void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s) {
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
                         float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
                         const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s) {
-    if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     PqJob j0{img0, bias0, p0, q0}, j1{img1, bias1, p1, q1};
+    // opt-in (RNAMPNN_NODE_RNA=1): measured SLOWER on C2 - 39.6 us per layer against 24.6 + 10.3 us of the two-kernel form: one
+    // workgroup per CU walks three dependent passes over its rows plus the image staging, with nothing else to hide them behind
+    static const bool use_rna = [] { const char* e = getenv("RNAMPNN_NODE_RNA"); return e && e[0] == '1'; }();
+    if (scale && pk.T <= 256 && use_rna) {      // one workgroup per RNA: statistics + normalisation + projections in one launch
+        static DevAttr a1, a2;
+        const size_t l1 = 65536 + 1024 + 1024 + 2048, l2 = 131072 + 1024 + 1024 + 2048;
+        ensure_dyn_lds((const void*)k_node_rna<1>, l1, a1);
+        ensure_dyn_lds((const void*)k_node_rna<2>, l2, a2);
+        if (njobs == 1) hipLaunchKernelGGL(k_node_rna<1>, dim3(pk.B), dim3(256), l1, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1);
+        else hipLaunchKernelGGL(k_node_rna<2>, dim3(pk.B), dim3(256), l2, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1);
+        return;
+    }
+    if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     dim3 grid((pk.Nmax + 127) / 128);
     static DevAttr attr1, attr2;
     ensure_dyn_lds((const void*)k_node_update<1>, 65536 + 1024, attr1);
