@@ -874,8 +874,11 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
 #else
 #define RN_EE_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef EE_WAVES
+#define EE_WAVES 8                // waves per workgroup; two workgroups (61 KiB of LDS each) per CU
+#endif
 template <bool SMALLK>
-__global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, const float* __restrict__ geomh,
+__global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16(PackInfo pk, int k, const float* __restrict__ geomh,
         const int* __restrict__ nbr, const bf16_t* __restrict__ img_g, const float* __restrict__ b0,
         const float* __restrict__ b1p, bf16_t* __restrict__ e) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -886,11 +889,12 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
     if (tid < 128) lds_b[tid] = b0[tid];                                        // of every edge block would expose an L2 round trip each
     else if (tid < 256) lds_b[tid] = b1p[tid - 128];
     {   // 60 KiB image: loads of a thread first, LDS writes after (see stage_image)
-        u32x4 t[8];
+        constexpr int NT = EE_WAVES * 64, PER = (NFRAG * 64 + NT - 1) / NT;
+        u32x4 t[PER];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = reinterpret_cast<const u32x4*>(img_g)[min(tid + i * 512, NFRAG * 64 - 1)];
+        for (int i = 0; i < PER; ++i) t[i] = reinterpret_cast<const u32x4*>(img_g)[min(tid + i * NT, NFRAG * 64 - 1)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (tid + i * 512 < NFRAG * 64) img[tid + i * 512] = t[i];
+        for (int i = 0; i < PER; ++i) if (tid + i * NT < NFRAG * 64) img[tid + i * NT] = t[i];
     }
     __syncthreads();
     const int ntot = pk.cu[pk.B];
@@ -900,7 +904,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
     const int q0 = SMALLK ? r / k : 0;
     const bool slot_ok = SMALLK ? q0 < npb : r < k;
     const int last_idx = ntot * k - 1;
-    const int stride = gridDim.x * 8;
+    const int stride = gridDim.x * EE_WAVES;
 
     // neighbour row of this lane's edge in block b (-1: no edge), addresses clamped, loads unconditional
     auto load_j = [&](int b) -> int {
@@ -914,10 +918,12 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
 #pragma unroll
         for (int v = 0; v < 7; ++v) nrec[v] = src[v];
     };
-    int blk = blockIdx.x * 8 + wave;
+    int blk = blockIdx.x * EE_WAVES + wave;
     if (blk >= nblocks) return;
     int j_cur = load_j(blk), j_nxt = load_j(blk + stride);
+#ifndef EE_NOPREFETCH
     load_rec(j_cur);
+#endif
 
     for (; blk < nblocks; blk += stride) {
         // ---- central record: wave-uniform pointer (k > 16) -> scalar loads; per-lane pointer otherwise
@@ -926,6 +932,9 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         auto catom = [&](int a, int d) { return a < 4 ? gc[3 * a + d] : gc[32 + 3 * (a - 4) + d]; };
         auto cbond = [&](int a, int d) { return a < 3 ? gc[12 + 3 * a + d] : gc[32 + 12 + 3 * (a - 3) + d]; };
         auto cnorm = [&](int a, int d) { return a < 2 ? gc[21 + 3 * a + d] : gc[32 + 21 + 3 * (a - 2) + d]; };
+#ifdef EE_NOPREFETCH
+        load_rec(j_cur);
+#endif
         float nl[28];
 #pragma unroll
         for (int v = 0; v < 7; ++v) { nl[4 * v] = nrec[v][0]; nl[4 * v + 1] = nrec[v][1]; nl[4 * v + 2] = nrec[v][2]; nl[4 * v + 3] = nrec[v][3]; }
@@ -961,7 +970,9 @@ __global__ void __launch_bounds__(512, 2) k_edge_embed_bf16(PackInfo pk, int k, 
         RN_EE_FENCE();
         // ---- requests of the next two blocks (their latency passes under this block's matrix work)
         const unsigned vmask = j_cur >= 0 ? 0xffffffffu : 0u;
+#ifndef EE_NOPREFETCH
         load_rec(j_nxt);
+#endif
         j_cur = j_nxt;
         j_nxt = load_j(blk + 2 * stride);
         RN_EE_FENCE();
@@ -1007,12 +1018,12 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geomh, const
                             const float* b0, const float* b1p, bf16_t* e, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
-    int grid = (max_blocks + 7) / 8;
+    int grid = (max_blocks + EE_WAVES - 1) / EE_WAVES;
     if (grid > 2 * num_cus()) grid = 2 * num_cus();
     if (grid < 1) grid = 1;
     size_t lds = (size_t)(4 * EMB_KS + 32) * 1024 + 1024;
-    if (k > 16) hipLaunchKernelGGL(k_edge_embed_bf16<false>, dim3(grid), dim3(512), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
-    else hipLaunchKernelGGL(k_edge_embed_bf16<true>, dim3(grid), dim3(512), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
+    if (k > 16) hipLaunchKernelGGL(k_edge_embed_bf16<false>, dim3(grid), dim3(EE_WAVES * 64), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
+    else hipLaunchKernelGGL(k_edge_embed_bf16<true>, dim3(grid), dim3(EE_WAVES * 64), lds, s, pk, k, geomh, nbr, img, b0, b1p, e);
 }
 
 // ------------------------------------------------------------------------------------------
