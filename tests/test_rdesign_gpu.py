@@ -1,0 +1,104 @@
+"""GPU parity of the `rdesign` row: `rdesign_forward` / `rdesign_readout` through the C ABI vs the CPU
+restatement oracle/rdesign_oracle.py on the same seeded inputs.  PARITY UNPINNED: the oracle itself has no reference-produced
+vector behind it (see its header); these tests pin the HIP path to the restatement, not to the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdesign_oracle as O
+from test_rdesign_cpu import _batch, _weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg_kw, precision, seed=0):
+    from rdesign.model.rdesign import RNAModel
+    m = RNAModel(precision=precision, **cfg_kw)
+    cfg = O.RDesignConfig(**cfg_kw)
+    sd = _weights(cfg, seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), cfg, sd
+
+
+CASES = [
+    (dict(k_neighbors=6, num_mpnn_layers=2), [12, 4, 9]),                       # an RNA shorter than k
+    (dict(), [40, 33, 25, 7]),                                                   # reference defaults: k=25, 9 layers, dense 256
+    (dict(k_neighbors=30, num_mpnn_layers=3, dim_dense_layers=512, num_readout_layers=2, readout_hidden_dim=128,
+          num_message_layers=2, num_dense_layers=1), [64, 1, 31]),              # a 1-residue RNA, hidden read-out layer
+]
+
+
+@pytest.mark.parametrize("kw,lengths", CASES)
+def test_features_and_graph_match_oracle(kw, lengths):
+    m, cfg, sd = _model(kw, "f32")
+    X, mask = _batch(lengths, seed=5)
+    out = m._run(X, mask, want=("edge_index", "node_raw", "edge_raw"))
+    node, edge, E_idx, attend = O.raw_features(X, mask, cfg)
+    got_idx = out["edge_index"].cpu()
+    assert ((got_idx >= 0) == attend).all()                                       # the reference's mask_attend filter
+    assert (got_idx[attend] == E_idx[attend]).all()                              # bit-exact neighbour lists
+    mb = mask == 1
+    assert (out["node_raw"].cpu() - node[mb]).abs().max() < 2e-5
+    K = cfg.k_neighbors
+    got_e = out["edge_raw"].cpu().view(-1, K, 115)
+    ref_e = edge[mb]
+    att = attend[mb]
+    assert (got_e[att] - ref_e[att]).abs().max() < 5e-5
+    assert got_e[~att].abs().max() == 0 if (~att).any() else True
+
+
+@pytest.mark.parametrize("kw,lengths", CASES)
+def test_forward_f32_matches_oracle(kw, lengths):
+    m, cfg, sd = _model(kw, "f32")
+    X, mask = _batch(lengths, seed=5)
+    S = torch.zeros(mask.shape, dtype=torch.long)
+    h_V, S_p = m(X, S, mask)
+    ref_h, ref_logits = O.forward(X, mask, sd, cfg)
+    assert h_V.shape == ref_h.shape and S_p.shape == (int(mask.sum()),)
+    assert (h_V.cpu() - ref_h).abs().max() < 2e-4                                 # tolerance: f32, LayerNorm-bounded activations
+    logits = m.readout(h_V)
+    assert (logits.cpu() - ref_logits).abs().max() < 2e-4
+    assert (m.forward_logits(X, mask).cpu() - ref_logits).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("kw,lengths", CASES[:2])
+def test_forward_bf16_within_tolerance(kw, lengths):
+    m, cfg, sd = _model(kw, "bf16")
+    X, mask = _batch(lengths, seed=5)
+    ref_h, ref_logits = O.forward(X, mask, sd, cfg)
+    out = m._run(X, mask, want=("h_V", "logits"))
+    # bf16 MFMA operands, f32 accumulate: every layer ends in a LayerNorm (unit-variance rows), tolerance 5e-2 absolute on h_V
+    assert (out["h_V"].cpu() - ref_h).abs().max() < 5e-2
+    assert (out["logits"].cpu() - ref_logits).abs().max() < 5e-2
+
+
+def test_batch_independence_and_predict(tmp_path):
+    """An RNA's rows do not depend on its batch mates as long as the padded length is the same tensor length (the flattened-chain
+    features of the last residues see the padding, feature.py:85-101) - and predict() writes the reference's CSV."""
+    m, cfg, sd = _model(dict(k_neighbors=8, num_mpnn_layers=2), "f32")
+    X, mask = _batch([20, 14, 9], seed=2)
+    both = m.forward_logits(X, mask)
+    alone = m.forward_logits(X[1:2], mask[1:2])
+    assert (both[20:34] - alone).abs().max() < 1e-5
+    S = torch.zeros(mask.shape, dtype=torch.long)
+    m.predict((X, S, mask, np.array([20, 14, 9]), ["a", "b", "c"]), 0, str(tmp_path), "o.csv")
+    rows = open(tmp_path / "o.csv").read().strip().split("\n")
+    assert rows[0] == "pdb_id,seq" and [len(r.split(",")[1]) for r in rows[1:]] == [20, 14, 9]
+    want = "".join("AUCG"[i] for i in both.argmax(-1).tolist())
+    assert "".join(r.split(",")[1] for r in rows[1:]) == want
+    r = m.validation_step((X, S, mask, [20, 14, 9], None))
+    assert len(r["recovery_rates"]) == 3 and torch.isfinite(r["validation loss"])
+
+
+def test_large_batch_properties():
+    """C2-sized batch (64 x <=500 nt): finite, padding-free packing, deterministic run to run."""
+    from rnampnn.utils import synth
+    m, cfg, sd = _model(dict(), "bf16")
+    lens = [int(v) for v in synth.synth_lengths(64, 100, 500, seed=3)]
+    X, mask = _batch(lens, seed=7)
+    a = m._run(X, mask, want=("h_V", "logits"))
+    b = m._run(X, mask, want=("h_V", "logits"))
+    assert a["h_V"].shape == (sum(lens), 128) and torch.isfinite(a["h_V"]).all()
+    assert torch.equal(a["logits"], b["logits"])
+    # every row is LayerNorm output: mean 0 / variance 1 under the affine (gain ~ 1 +- 0.1 here) - a cheap global sanity bound
+    assert a["h_V"].abs().max() < 20
