@@ -62,3 +62,29 @@ void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels,
                  hipStream_t s);
 void t_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
                  int step, hipStream_t s);
+
+// ---- bf16-STORAGE edge kernels of the bf16-mixed trainer (kernels_train.hip, last part).  Under the reference's bf16 autocast
+// (rnampnn/utils/train.py:109) every nn.Linear output - hence the whole per-edge chain e, pre-activations and their gradients - is a
+// bf16 tensor; here all [E][128] tensors of the ResMPNN layers are bf16 row-major in HBM (half the bytes of the f32 tape), f32
+// only inside the kernels (MFMA accumulators, GELU, sums).  `tb16` = raw bf16 bits, round-to-nearest-even on store.
+typedef unsigned short tb16;
+struct EFuse {                       // optional epilogue fusions of te_gemm
+    const float* pq;                 // v += P[row / k] + Q[nbr[row]]       (pq [N+1][256] f32: P | Q, row `zero_row` = zeros)
+    const int* nbr; int k; int zero_row;
+    const tb16* res_in; tb16* res_out;   // res_out = res_in + (nbr[row] >= 0 ? drop(gelu(v), site2) : 0)     (edge update, mpnn.py:250-262)
+    unsigned site2;
+};
+// Y[R][128] (bf16) = [beta Y] + actA(X)[R][128] . W' + bias, [* gelu'(epi_pre) * mask(site)]; W' = W^T (w_rows: W [128][ldw] as
+// nn.Linear stores it) or W (W [128][ldw] k-major).  X is bf16 (x_bf16) or f32, row stride ldx.
+void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
+             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s);
+// dW[128][ldw] += A^T . actB(B), dbias += colsum(A)     (A, B bf16 [R][128])
+void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
+                unsigned site, float* dbias, hipStream_t s);
+void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s);
+void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
+void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
+void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);
+void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s);
+void te_gelu_fwd_out(const TRows& rows, const float* x, tb16* y, int D, const TDrop& dr, unsigned site, hipStream_t s);      // y = bf16(drop(gelu(x)))
+void te_gelu_bwd_in(const TRows& rows, const tb16* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site, hipStream_t s);   // dx = dy gelu'(pre) mask

@@ -1078,3 +1078,408 @@ void t_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
 }
+
+// ==========================================================================================
+// bf16-STORAGE edge kernels of the bf16-mixed trainer (declared at the end of kernels_train.h).
+__device__ __forceinline__ float tbf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float tbf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float tbf(tb16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ tb16 to_tb(float v) { return (tb16)(tpack2(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ void unpack8(const tu32x4& u, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = tbf_lo(u[i]); v[2 * i + 1] = tbf_hi(u[i]); }
+}
+
+struct EmmArgs {
+    TRows rows;
+    const void* X; int ldx;
+    const float* W; int ldw; const float* bias;
+    tb16* Y; int beta; int actA; const tb16* epi_pre;
+    EFuse f; int has_pq, has_res;
+    TDrop dr; unsigned site;
+};
+// The [E][128] x [128][128] GEMM of the per-edge Linears with the output TRANSPOSED in the accumulators: D = W' . X^T, i.e. the weight
+// is the A operand (its rows permuted so that a lane's 16 accumulator registers of a 32-channel block are two runs of 8 CONSECUTIVE
+// channels) and the 32 edge rows of a tile are the B operand (lane (r, h) = 8 consecutive k of row r: one 16-byte bf16 load).  Every
+// lane then owns 64 channels of ITS edge row: the epilogue's loads / stores (old Y, taped pre-activation, P / Q rows, residual input,
+// outputs) are all 16-byte row-contiguous accesses, and row-wise data (neighbour index, validity) is per lane.  The whole weight lives in
+// registers (128 VGPRs of A fragments, one wave per SIMD), a wave streams 32-row tiles past it with the next tile's X in flight.
+template <bool B_ROWS, typename TX>
+__global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short img[32 * 64 * 8];      // [ks][cb][lane][8] bf16 A fragments
+    __shared__ __attribute__((aligned(16))) float lds_bias[128];
+    const int R = nrows(a.rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const float* __restrict__ W = a.W;
+    for (int e = tid; e < 128 * 64; e += 256) {
+        int k, c;
+        float v0, v1;
+        if (B_ROWS) { c = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)c * a.ldw + k; v0 = p[0]; v1 = p[1]; }
+        else { k = 2 * (e >> 7); c = e & 127; v0 = W[(size_t)k * a.ldw + c]; v1 = W[(size_t)(k + 1) * a.ldw + c]; }
+        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = c >> 5, c5 = c & 31;
+        const int i = 8 * (c5 >> 4) + (c5 & 7), hq = (c5 >> 3) & 1, rho = (i & 3) + 8 * (i >> 2) + 4 * hq;
+        *reinterpret_cast<unsigned*>(img + (((ks * 4 + cb) * 64 + hh * 32 + rho) * 8 + j)) = tpack2(v0, v1);
+    }
+    if (tid < 128) lds_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+    __syncthreads();
+    tu32x4 wf[8][4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) wf[ks][cb] = reinterpret_cast<const tu32x4*>(img)[(ks * 4 + cb) * 64 + lane];
+    const int ntiles = (R + 31) / 32;
+    const int tstride = gridDim.x * 4;
+    constexpr bool XB = sizeof(TX) == 2;
+    tu32x4 rawb[8];                    // bf16 X: the fragments themselves
+    tf32x4 rawf[XB ? 1 : 16];          // f32 X
+    int jn = -1;                       // neighbour of the prefetched tile's row
+    const TX* __restrict__ X = reinterpret_cast<const TX*>(a.X);
+    auto load_raw = [&](int t) {
+        const int row = min(32 * t + r, R - 1);
+        const TX* p = X + (size_t)row * a.ldx + 8 * h;
+        if constexpr (XB) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) rawb[ks] = *reinterpret_cast<const tu32x4*>(p + 16 * ks);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                rawf[2 * ks] = *reinterpret_cast<const tf32x4*>(p + 16 * ks);
+                rawf[2 * ks + 1] = *reinterpret_cast<const tf32x4*>(p + 16 * ks + 4);
+            }
+        }
+        if (a.f.nbr) jn = a.f.nbr[row];
+    };
+    int t = blockIdx.x * 4 + wave;
+    if (t < ntiles) load_raw(t);
+    for (; t < ntiles; t += tstride) {
+        const int row = 32 * t + r;
+        const bool rok = row < R;
+        const int rowc = rok ? row : R - 1;
+        const int j = jn;
+        tu32x4 xf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (XB && !a.actA) { xf[ks] = rawb[ks]; }
+            else {
+                float v[8];
+                if constexpr (XB) unpack8(rawb[ks], v);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = rawf[2 * ks][q]; v[4 + q] = rawf[2 * ks + 1][q]; }
+                }
+                if (a.actA) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * drop_mul(a.dr, a.site, (unsigned long long)row * 128 + 16 * ks + 8 * h + q);
+                }
+                xf[ks] = tpack8(v);
+            }
+            if (!rok) xf[ks] = tu32x4{0u, 0u, 0u, 0u};
+        }
+        if (t + tstride < ntiles) load_raw(t + tstride);
+        tf32x16 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wf[ks][cb], xf[ks], acc[cb]);
+        // ---- epilogue: this lane's row, channels c0 .. c0+7 and c0+16 .. c0+23 of every 32-channel block
+        const float* prow = nullptr;
+        const float* qrow = nullptr;
+        if (a.has_pq) {
+            prow = a.f.pq + (size_t)(rowc / a.f.k) * 256;
+            qrow = a.f.pq + (size_t)(j < 0 ? a.f.zero_row : (j > a.f.zero_row ? a.f.zero_row : j)) * 256 + 128;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c0 = 32 * cb + 8 * h;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[cb][i];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int c = c0 + 16 * g;
+                const tf32x4 b0 = *reinterpret_cast<const tf32x4*>(lds_bias + c), b1 = *reinterpret_cast<const tf32x4*>(lds_bias + c + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[8 * g + q] += b0[q]; v[8 * g + 4 + q] += b1[q]; }
+                if (a.has_pq) {
+                    const tf32x4 p0 = *reinterpret_cast<const tf32x4*>(prow + c), p1 = *reinterpret_cast<const tf32x4*>(prow + c + 4);
+                    const tf32x4 q0 = *reinterpret_cast<const tf32x4*>(qrow + c), q1 = *reinterpret_cast<const tf32x4*>(qrow + c + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[8 * g + q] += p0[q] + q0[q]; v[8 * g + 4 + q] += p1[q] + q1[q]; }
+                }
+                if (a.epi_pre) {
+                    float pr[8];
+                    unpack8(*reinterpret_cast<const tu32x4*>(a.epi_pre + (size_t)rowc * 128 + c), pr);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[8 * g + q] *= gelu_d_fast(pr[q]) * drop_mul(a.dr, a.site, (unsigned long long)row * 128 + c + q);
+                }
+                if (a.beta) {
+                    float yo[8];
+                    unpack8(*reinterpret_cast<const tu32x4*>(a.Y + (size_t)rowc * 128 + c), yo);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[8 * g + q] += yo[q];
+                }
+                float o[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = v[8 * g + q];
+                if (rok) *reinterpret_cast<tu32x4*>(a.Y + (size_t)row * 128 + c) = tpack8(o);
+                if (a.has_res) {
+                    float ei[8];
+                    unpack8(*reinterpret_cast<const tu32x4*>(a.f.res_in + (size_t)rowc * 128 + c), ei);
+                    if (j >= 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) ei[q] += gelu_fast(o[q]) * drop_mul(a.dr, a.f.site2, (unsigned long long)row * 128 + c + q);
+                    }
+                    if (rok) *reinterpret_cast<tu32x4*>(a.f.res_out + (size_t)row * 128 + c) = tpack8(ei);
+                }
+            }
+        }
+    }
+}
+void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
+             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s) {
+    EmmArgs a;
+    a.rows = rows; a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y; a.beta = beta; a.actA = actA ? 1 : 0;
+    a.epi_pre = epi_pre; a.dr = dr; a.site = site;
+    if (fuse) a.f = *fuse; else a.f = EFuse{nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
+    a.has_pq = a.f.pq != nullptr; a.has_res = a.f.res_out != nullptr;
+    const dim3 grid(mm128_grid(rows));
+    if (w_rows) {
+        if (x_bf16) hipLaunchKernelGGL((k_emm128<true, tb16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_emm128<true, float>), grid, dim3(256), 0, s, a);
+    } else {
+        if (x_bf16) hipLaunchKernelGGL((k_emm128<false, tb16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_emm128<false, float>), grid, dim3(256), 0, s, a);
+    }
+}
+
+// ---- TN with bf16 operands: dW[n][kk] += sum_m A[m][n] actB(B[m][kk]), M = K = 128.  Same scheme as k_mm_tn (64-row tiles row-major
+// in LDS, transposed fragment reads, row range split over blockIdx.z, ordered reduction of the partial tiles); the staging is a straight
+// 16-byte copy unless the activation prologue is on.
+__global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restrict__ A, const tb16* __restrict__ B, float* __restrict__ part,
+        int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+    __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
+    __shared__ float cs_red[16][128];
+    const int R = nrows(rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
+    const int ch = tid & 15, rg = tid >> 4;                   // 16-byte chunk ch of rows rg, rg+16, rg+32, rg+48
+    tu32x4 ra[4], rb[4];
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rg + 16 * i;
+            const bool ok = m < p_end;
+            const int mc = ok ? m : (R > 0 ? R - 1 : 0);
+            tu32x4 va = *reinterpret_cast<const tu32x4*>(A + (size_t)mc * 128 + 8 * ch);
+            tu32x4 vb = *reinterpret_cast<const tu32x4*>(B + (size_t)mc * 128 + 8 * ch);
+            if (actB) {
+                float v[8];
+                unpack8(vb, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * drop_mul(dr, site, (unsigned long long)m * 128 + 8 * ch + q);
+                vb = tpack8(v);
+            }
+            if (!ok) { va = tu32x4{0u, 0u, 0u, 0u}; vb = va; }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    tf32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    if (p_begin < p_end) load_tile(p_begin);
+    for (int m0 = p_begin; m0 < p_end; m0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = ra[i];
+            *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = rb[i];
+        }
+        if (cs_part) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+                unpack8(ra[i], v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) csum[q] += v[q];
+            }
+        }
+        __syncthreads();
+        if (m0 + 64 < p_end) load_tile(m0 + 64);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tu32x4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(tA, 16 * ks, 64 * wr + 32 * a, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(tB, 16 * ks, 64 * wc + 32 * b, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+        }
+    }
+    if (cs_part) {                                            // rows rg, rg+16, ... were summed per thread: fold the 16 row groups in order
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs_red[rg][8 * ch + q] = csum[q];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += cs_red[g][tid];
+            cs_part[(size_t)blockIdx.z * 128 + tid] = t;
+        }
+    }
+    float* dst = part + (size_t)blockIdx.z * 128 * 128;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = 64 * wc + 32 * b + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(size_t)(64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[a][b][i];
+        }
+}
+void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
+                unsigned site, float* dbias, hipStream_t s) {
+    const size_t mk = 128 * 128;
+    long long cap = (long long)((sc.floats - (size_t)520 * 128) / mk) - 16;
+    int splits = (rows.maxrows + 1023) / 1024;
+    const int want = 2 * rn_num_cus();
+    if (splits > want) splits = want;
+    if (splits > cap) splits = (int)cap;
+    if (splits > 500) splits = 500;
+    if (splits < 1) splits = 1;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    float* tmp = sc.p + (size_t)splits * mk;
+    float* cs = dbias ? tmp + 16 * mk : nullptr;
+    hipLaunchKernelGGL(k_emm_tn, dim3(1, 1, splits), dim3(256), 0, s, rows, A, B, sc.p, rps, actB ? 1 : 0, dr, site, cs);
+    reduce_parts(sc.p, splits, mk, (int)mk, 128, dW, ldw, s, tmp);
+    if (dbias) reduce_parts(cs, splits, (size_t)128, 128, 128, dbias, 128, s, cs + (size_t)splits * 128);
+}
+
+// ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
+__global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const tb16* __restrict__ pre2,
+                                                   const float* __restrict__ hin, float* __restrict__ out, TDrop dr, unsigned site) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= pk.cu[pk.B]) return;
+    const int c = 2 * (threadIdx.x & 63);
+    float s0 = 0.f, s1 = 0.f;
+    int cnt = 0;
+    for (int sl = 0; sl < k; ++sl) {
+        const size_t er = (size_t)p * k + sl;
+        if (nbr[er] >= 0) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
+            s0 += gelu_fast(tbf_lo(w)) * drop_mul(dr, site, er * RN_D + c);
+            s1 += gelu_fast(tbf_hi(w)) * drop_mul(dr, site, er * RN_D + c + 1);
+            ++cnt;
+        }
+    }
+    const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
+    const tf32x2 hv = *reinterpret_cast<const tf32x2*>(hin + (size_t)p * RN_D + c);
+    *reinterpret_cast<tf32x2*>(out + (size_t)p * RN_D + c) = tf32x2{hv[0] + s0 * inv, hv[1] + s1 * inv};
+}
+__global__ void __launch_bounds__(256) k_eseg_mean_bwd(PackInfo pk, int k, const int* __restrict__ nbr, const float* __restrict__ dagg,
+                                                       const tb16* __restrict__ pre2, tb16* __restrict__ dpre2, TDrop dr, unsigned site) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= pk.cu[pk.B]) return;
+    const int c = 2 * (threadIdx.x & 63);
+    int cnt = 0;
+    for (int sl = 0; sl < k; ++sl) cnt += nbr[(size_t)p * k + sl] >= 0;
+    const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
+    const tf32x2 g = *reinterpret_cast<const tf32x2*>(dagg + (size_t)p * RN_D + c);
+    for (int sl = 0; sl < k; ++sl) {
+        const size_t er = (size_t)p * k + sl;
+        unsigned o = 0u;
+        if (nbr[er] >= 0) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
+            o = tpack2(g[0] * inv * gelu_d_fast(tbf_lo(w)) * drop_mul(dr, site, er * RN_D + c),
+                       g[1] * inv * gelu_d_fast(tbf_hi(w)) * drop_mul(dr, site, er * RN_D + c + 1));
+        }
+        *reinterpret_cast<unsigned*>(dpre2 + er * RN_D + c) = o;
+    }
+}
+void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_eseg_mean, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, pre2, h, out, dr, site);
+}
+void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_eseg_mean_bwd, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, dagg, pre2, dpre2, dr, site);
+}
+// mode 0: dpre2 = valid ? de * gelu'(pre2) * mask : 0;  mode 1: x = 0 on invalid slots       (16-byte units: 8 channels)
+__global__ void k_eelem(PackInfo pk, int k, const int* __restrict__ nbr, int mode, const tb16* __restrict__ de, const tb16* __restrict__ pre2,
+                        tb16* __restrict__ x, TDrop dr, unsigned site) {
+    const size_t n = (size_t)pk.cu[pk.B] * k * 16;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (size_t)gridDim.x * blockDim.x) {
+        const bool valid = nbr[id >> 4] >= 0;
+        tu32x4* xp = reinterpret_cast<tu32x4*>(x) + id;
+        if (mode == 1) { if (!valid) *xp = tu32x4{0u, 0u, 0u, 0u}; continue; }
+        tu32x4 o = {0u, 0u, 0u, 0u};
+        if (valid) {
+            float d[8], pr[8];
+            unpack8(reinterpret_cast<const tu32x4*>(de)[id], d);
+            unpack8(reinterpret_cast<const tu32x4*>(pre2)[id], pr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] *= gelu_d_fast(pr[q]) * drop_mul(dr, site, id * 8 + q);
+            o = tpack8(d);
+        }
+        *xp = o;
+    }
+}
+static unsigned eelem_grid(const PackInfo& pk, int k) { size_t g = ((size_t)pk.Nmax * k * 16 + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
+void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 0, de, pre2, dpre2, dr, site);
+}
+void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s) {
+    hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, nullptr, x, TDrop{0, 0, 1.f}, 0u);
+}
+__global__ void __launch_bounds__(256) k_epq_bwd(PackInfo pk, int k, const tb16* __restrict__ dpre1, const int* __restrict__ start,
+                                                 const int* __restrict__ list, float* __restrict__ dpq) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= pk.cu[pk.B]) return;
+    const int c = 2 * (threadIdx.x & 63);
+    float s0 = 0.f, s1 = 0.f;
+    for (int sl = 0; sl < k; ++sl) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(dpre1 + ((size_t)p * k + sl) * RN_D + c);
+        s0 += tbf_lo(w); s1 += tbf_hi(w);
+    }
+    *reinterpret_cast<tf32x2*>(dpq + (size_t)p * 256 + c) = tf32x2{s0, s1};
+    float q0 = 0.f, q1 = 0.f;
+    for (int t = start[p]; t < start[p + 1]; ++t) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(dpre1 + (size_t)list[t] * RN_D + c);
+        q0 += tbf_lo(w); q1 += tbf_hi(w);
+    }
+    *reinterpret_cast<tf32x2*>(dpq + (size_t)p * 256 + 128 + c) = tf32x2{q0, q1};
+}
+void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* start, const int* list, float* dpq, hipStream_t s) {
+    hipLaunchKernelGGL(k_epq_bwd, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, dpre1, start, list, dpq);
+}
+__global__ void k_egelu_fwd_out(TRows rows, const float* __restrict__ x, tb16* __restrict__ y, int D, TDrop dr, unsigned site) {
+    const size_t n = (size_t)nrows(rows) * D / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const tf32x2 v = reinterpret_cast<const tf32x2*>(x)[i];
+        reinterpret_cast<unsigned*>(y)[i] = tpack2(gelu_f(v[0]) * drop_mul(dr, site, 2 * i), gelu_f(v[1]) * drop_mul(dr, site, 2 * i + 1));
+    }
+}
+__global__ void k_egelu_bwd_in(TRows rows, const tb16* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int D, TDrop dr, unsigned site) {
+    const size_t n = (size_t)nrows(rows) * D / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned w = reinterpret_cast<const unsigned*>(dy)[i];
+        const tf32x2 p = reinterpret_cast<const tf32x2*>(pre)[i];
+        reinterpret_cast<tf32x2*>(dx)[i] = tf32x2{tbf_lo(w) * gelu_d(p[0]) * drop_mul(dr, site, 2 * i), tbf_hi(w) * gelu_d(p[1]) * drop_mul(dr, site, 2 * i + 1)};
+    }
+}
+void te_gelu_fwd_out(const TRows& rows, const float* x, tb16* y, int D, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_egelu_fwd_out, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, x, y, D, dr, site);
+}
+void te_gelu_bwd_in(const TRows& rows, const tb16* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_egelu_bwd_in, dim3(ew_grid(rows, D)), dim3(256), 0, s, rows, dy, pre, dx, D, dr, site);
+}

@@ -170,7 +170,8 @@ class RNAModel(nn.Module):
         B, T = int(X.shape[0]), int(X.shape[1])
         if B == 0 or T == 0:
             raise ValueError("empty batch")
-        self._check_mask(mask)
+        if n_valid is None:                      # a caller that passes n_valid vouches for the mask (no host sync on the hot path)
+            self._check_mask(mask)
         n = int(mask.sum().item()) if n_valid is None else n_valid
         Xd, md = _prep(X, dev), _prep(mask, dev)
         K = self.hparams["k_neighbors"]

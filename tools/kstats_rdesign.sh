@@ -1,0 +1,18 @@
+#!/bin/bash
+# per-kernel time of the rdesign forward under rocprofv3 --kernel-trace.  usage: tools/kstats_rdesign.sh <outdir> [precision]
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$1; shift; mkdir -p $OUT
+python3 $ROOT/__graft_entry__.py || exit 1
+python3 $ROOT/tools/rdesign_probe.py ${1:-bf16} 20 > $OUT/probe.json 2>$OUT/probe.err || exit 1
+cat $OUT/probe.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/rdesign_probe.py ${1:-bf16} 10 > $OUT/prof.log 2>&1
+python3 - <<PY
+import csv, glob
+f = sorted(glob.glob("$OUT/*/*kernel_stats.csv"))[-1]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:16]:
+    print(f"{r['Name'][:70]:70s} n {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.1f} us  /step {float(r['TotalDurationNs'])/13/1e3:8.1f} us {float(r['Percentage']):5.1f}%")
+print('sum per step us', round(tot/13/1e3, 1))
+PY

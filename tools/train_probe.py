@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step throughput (taped forward + HIP backward + fused Adam) at the C2 shape.
-usage: python tools/train_probe.py [B=64] [precision=bf16|f32] [steps=5]"""
+usage: python tools/train_probe.py [B=64] [precision=bf16|f32] [steps=5] [lo=100] [hi=140]   (C2 shape: lo=100 hi=500)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rna-mpnn_amd"))
 import torch
@@ -9,7 +9,9 @@ from rnampnn.utils import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-lens = synth.synth_lengths(B, 100, 140, seed=0)
+lo = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+hi = int(sys.argv[5]) if len(sys.argv) > 5 else 140
+lens = synth.synth_lengths(B, lo, hi, seed=0)
 coords, mask, labels = synth.synth_batch(lens)
 model = RNAMPNN(precision=prec, num_res_neighbours=30, padding_len=int(mask.shape[1])).to("cuda:0").train()
 (opt,), _ = model.configure_optimizers(fused=True)
