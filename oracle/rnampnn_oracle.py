@@ -73,20 +73,23 @@ def site_edge(layer: int, i: int) -> int:
 
 
 def dropout_multiplier(seed: int, site: int, idx, p: float):
-    """-> float32 numpy array of 0 or 1/(1-p) for the element indices ``idx`` (any integer array): the 32-bit counter hash
-    of csrc/kernels_train.hip (drop_mul), all arithmetic modulo 2^32."""
+    """-> float32 numpy array of 0 or 1/(1-p) for the element indices ``idx`` (any integer array): the counter hash of
+    csrc/kernels_train.hip (drop_mul / drop_pair), all arithmetic modulo 2^32.  One murmur3-finaliser hash per PAIR of elements
+    (2P, 2P + 1): its low 16 bits decide the even element, its high 16 bits the odd one; keep iff >= round(p * 65536)."""
     import numpy as np
     u32 = np.uint32
     i64 = np.asarray(idx).astype(np.uint64)
-    lo, hi = (i64 & np.uint64(0xFFFFFFFF)).astype(u32), (i64 >> np.uint64(32)).astype(u32)
+    pair = i64 >> np.uint64(1)
+    lo, hi = (pair & np.uint64(0xFFFFFFFF)).astype(u32), (pair >> np.uint64(32)).astype(u32)
     const = (int(site) * 0x85EBCA6B + (int(seed) & 0xFFFFFFFF) + ((int(seed) >> 32) & 0xFFFFFFFF) * 0x27D4EB2F) & 0xFFFFFFFF
     with np.errstate(over="ignore"):
-        x = lo * u32(0x9E3779B1) + hi * u32(0xC2B2AE35) + u32(const)
+        x = lo + hi * u32(0xC2B2AE35) + u32(const)
         x ^= x >> u32(16); x *= u32(0x85EBCA6B)
         x ^= x >> u32(13); x *= u32(0xC2B2AE35)
         x ^= x >> u32(16)
-    thresh = int(np.float32(p) * np.float32(16777216.0))
-    keep = (x >> u32(8)).astype(np.int64) >= thresh
+    r16 = np.where((i64 & np.uint64(1)) == 1, x >> u32(16), x & u32(0xFFFF)).astype(np.int64)
+    thresh = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    keep = r16 >= thresh
     return np.where(keep, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
 
 

@@ -6,14 +6,16 @@ struct TRows { const int* ntot; int mul; int maxrows; };   // row count = *ntot 
 
 // Dropout of the training path (the reference: nn.Dropout(p) after every GELU, mpnn.py:140,150, feature.py:200,
 // functional.py:69,124,184, and on the attention probabilities, functional.py:109).  The keep decision of one element is a
-// pure function of (seed, site, element index): a 32-bit counter hash (murmur3 finaliser), restated by the CPU oracle, so that the HIP
-// forward / backward and the oracle's autograd see THE SAME mask.  element index = row * D + channel with rows in
-// the packed order (node row p, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
-struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // keep iff (hash32 >> 8) >= thresh (= p * 2^24); scale = 1/(1-p)
+// pure function of (seed, site, element index), restated by the CPU oracle, so that the HIP forward / backward and the oracle's
+// autograd see THE SAME mask.  One 32-bit counter hash (murmur3 finaliser) serves the PAIR of elements (2P, 2P + 1): the low
+// 16 bits decide the even element, the high 16 bits the odd one (keep iff >= thresh = round(p * 65536)): the kernels that own 8
+// consecutive channels of a row pay 4 hashes for 8 decisions.  element index = row * D + channel with rows in the packed order
+// (node row p, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
+struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // scale = 1/(1-p)
 static inline TDrop t_drop(float p, unsigned long long seed) {
     TDrop d;
     d.seed = seed;
-    d.thresh = p > 0.f ? (unsigned)(p * 16777216.0f) : 0u;
+    d.thresh = p > 0.f ? (unsigned)(p * 65536.0f + 0.5f) : 0u;
     d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }
@@ -69,7 +71,7 @@ void t_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 // only inside the kernels (MFMA accumulators, GELU, sums).  `tb16` = raw bf16 bits, round-to-nearest-even on store.
 typedef unsigned short tb16;
 struct EFuse {                       // optional epilogue fusions of te_gemm
-    const float* pq;                 // v += P[row / k] + Q[nbr[row]]       (pq [N+1][256] f32: P | Q, row `zero_row` = zeros)
+    const tb16* P; const tb16* Q;    // v += P[row / k] + Q[nbr[row]]       (bf16 [N+1][128] each; row `zero_row` of Q = zeros)
     const int* nbr; int k; int zero_row;
     const tb16* res_in; tb16* res_out;   // res_out = res_in + (nbr[row] >= 0 ? drop(gelu(v), site2) : 0)     (edge update, mpnn.py:250-262)
     unsigned site2;

@@ -6,6 +6,8 @@
 // (loss = cross_entropy(softmax(logits)[valid], label), mean over valid nucleotides) and the forward
 // lines cited in kernels_f32.hip.  Dropout: counter-hash masks (TDrop, kernels_train.h); every cross-workgroup sum is an ordered two-stage reduction (no float atomics).
 #include "kernels_train.h"
+#include <cstdio>
+#include <cstdlib>
 
 static constexpr float kSEPS = 1.0e-6f;
 #define TLD 132
@@ -16,15 +18,33 @@ __device__ __forceinline__ float gelu_d(float x) {     // d/dx [x Phi(x)] = Phi(
 }
 __device__ __forceinline__ int nrows(const TRows& r) { return *r.ntot * r.mul; }
 // dropout multiplier of one element: 0 or 1/(1-p) (kernels_train.h: TDrop; restated by the oracle's dropout_multiplier).
-// 32-bit counter hash (murmur3 finaliser) of (seed, site, 64-bit element index): ~12 integer instructions, no 64-bit multiply.
-__device__ __forceinline__ float drop_mul(const TDrop& d, unsigned site, unsigned long long idx) {
-    if (d.thresh == 0u) return 1.f;
-    unsigned x = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0xC2B2AE35u + site * 0x85EBCA6Bu
-               + (unsigned)d.seed + (unsigned)(d.seed >> 32) * 0x27D4EB2Fu;
+__device__ __forceinline__ unsigned drop_key(const TDrop& d, unsigned site) {         // wave-uniform part of the hash input
+    return site * 0x85EBCA6Bu + (unsigned)d.seed + (unsigned)(d.seed >> 32) * 0x27D4EB2Fu;
+}
+__device__ __forceinline__ unsigned drop_hash(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu;
     x ^= x >> 13; x *= 0xC2B2AE35u;
     x ^= x >> 16;
-    return (x >> 8) >= d.thresh ? d.scale : 0.f;
+    return x;
+}
+__device__ __forceinline__ float drop_mul(const TDrop& d, unsigned site, unsigned long long idx) {
+    if (d.thresh == 0u) return 1.f;
+    const unsigned long long P = idx >> 1;
+    const unsigned x = drop_hash((unsigned)P + (unsigned)(P >> 32) * 0xC2B2AE35u + drop_key(d, site));
+    return ((idx & 1ull) ? x >> 16 : x & 0xffffu) >= d.thresh ? d.scale : 0.f;
+}
+// both elements of pair P (element indices 2P, 2P + 1) when P is known to fit 32 bits (every [rows][D] tensor of the trainer: the
+// entry points bound rows * D / 2 < 2^32); key = drop_key(d, site)
+__device__ __forceinline__ void drop_pair(const TDrop& d, unsigned key, unsigned P, float& m0, float& m1) {
+    if (d.thresh == 0u) { m0 = 1.f; m1 = 1.f; return; }
+    const unsigned x = drop_hash(P + key);
+    m0 = (x & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    m1 = (x >> 16) >= d.thresh ? d.scale : 0.f;
+}
+// the 8 multipliers of elements 8 * P8 .. 8 * P8 + 7  (P8 = element index / 8)
+__device__ __forceinline__ void drop8(const TDrop& d, unsigned key, unsigned P8, float (&m)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) drop_pair(d, key, 4u * P8 + q, m[2 * q], m[2 * q + 1]);
 }
 // GELU and its derivative for the fused prologues / epilogues of the bf16-mixed GEMMs: Phi(x) ~ sigmoid(x (c0 + c1 x^2)),
 // coefficients minimax-fitted to the erf form (max |x Phi - gelu| 2.7e-4, below the bf16 rounding of the operands these
@@ -95,13 +115,15 @@ void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, 
 
 // Ordered reduction of partial results: out[(i / cols) * ld_out + i % cols] += sum_{s < nparts} part[s * count + i], s ascending.
 // Every cross-workgroup sum of the backward goes through this (no float atomics): gradients are bit-reproducible.
+// Elements i >= split_at belong to a second, dense output (the bias gradient riding behind a weight-gradient tile): out2[i - split_at].
 __global__ void k_reduce_parts(const float* __restrict__ part, int nparts, size_t stride, int count, int cols,
-                               float* __restrict__ out, int ld_out) {
+                               float* __restrict__ out, int ld_out, int split_at, float* __restrict__ out2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float s = 0.f;
     for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];
-    out[(size_t)(i / cols) * ld_out + (i % cols)] += s;
+    if (i < split_at) out[(size_t)(i / cols) * ld_out + (i % cols)] += s;
+    else out2[i - split_at] += s;
 }
 // first level of a two-level reduction: group g sums its contiguous run of partials (ascending) into tmp[g][count]
 __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size_t stride, int count, int per_group,
@@ -115,14 +137,15 @@ __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size
 }
 // (the association order is a function of nparts alone: bit-reproducible.  tmp: 16 * count floats behind the partials)
 static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s,
-                         float* tmp = nullptr) {
-    if (tmp && nparts > 32) {
+                         float* tmp = nullptr, int split_at = -1, float* out2 = nullptr) {
+    if (split_at < 0) split_at = count;
+    if (tmp && nparts > 96) {
         const int G = 16, per = (nparts + G - 1) / G;
         hipLaunchKernelGGL(k_reduce_groups, dim3((count + 255) / 256, G), dim3(256), 0, s, part, nparts, stride, count, per, tmp);
-        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out, split_at, out2);
         return;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out, split_at, out2);
 }
 
 // dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block; the row range is split over blockIdx.z, every split
@@ -415,46 +438,50 @@ void t_edge_pq_bwd(const PackInfo& pk, int k, const float* dpre1, const int* sta
 //   dL/dvar = -0.5 sd^-3 sum g_i (x_i - mu),   dL/dmu = -sum g_i / sd + dL/dvar * 2 c mu / n
 __global__ void __launch_bounds__(256) k_gn_bwd(PackInfo pk, const float* __restrict__ x, const float* __restrict__ dy,
         const float* __restrict__ scale, int t_tot, float* __restrict__ dx, float* __restrict__ part) {
-    __shared__ float red[4][256];
+    // grid (RNA, 32-channel chunk): thread = (channel c of the chunk, row group rg of 8); the 8 groups are folded in fixed order
+    __shared__ float red[3][8][32];
     const int b = blockIdx.x;
     const int n = pk.len[b];
-    if (n <= 0) { part[(size_t)b * 256 + threadIdx.x] = 0.f; return; }      // [b][dscale 128 | dshift 128]
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    if (n <= 0) { if (rg == 0) { part[(size_t)b * 256 + c] = 0.f; part[(size_t)b * 256 + 128 + c] = 0.f; } return; }      // [b][dscale 128 | dshift 128]
     const size_t base = (size_t)pk.cu[b] * RN_D;
-    const int c = threadIdx.x & 127, hf = threadIdx.x >> 7;
     const float* xb = x + base;
     const float* gb = dy + base;
+    auto fold = [&](int w) { float t = 0.f; for (int g = 0; g < 8; ++g) t += red[w][g][cl]; return t; };
     float s = 0.f;
-    for (int r = hf; r < n; r += 2) s += xb[(size_t)r * RN_D + c];
-    red[0][threadIdx.x] = s;
+    for (int r = rg; r < n; r += 8) s += xb[(size_t)r * RN_D + c];
+    red[0][rg][cl] = s;
     __syncthreads();
-    const float mean = (red[0][c] + red[0][c + 128]) / (float)n;
+    const float mean = fold(0) / (float)n;
+    __syncthreads();
     float ss = 0.f, sg = 0.f, sgx = 0.f;
-    for (int r = hf; r < n; r += 2) {
+    for (int r = rg; r < n; r += 8) {
         const float d = xb[(size_t)r * RN_D + c] - mean, g = gb[(size_t)r * RN_D + c];
         ss = fmaf(d, d, ss); sg += g; sgx = fmaf(g, d, sgx);
     }
-    red[1][threadIdx.x] = ss; red[2][threadIdx.x] = sg; red[3][threadIdx.x] = sgx;
+    red[0][rg][cl] = ss; red[1][rg][cl] = sg; red[2][rg][cl] = sgx;
     __syncthreads();
     const float cpad = (float)(t_tot - n), fn = (float)n;
-    const float var = (red[1][c] + red[1][c + 128] + cpad * mean * mean) / fn + kSEPS;
+    const float Ss = fold(0), Sg0 = fold(1), Sgx0 = fold(2);
+    const float var = (Ss + cpad * mean * mean) / fn + kSEPS;
     const float sd = sqrtf(var), sc = scale[c];
-    const float Sg = (red[2][c] + red[2][c + 128]) * sc, Sgx = (red[3][c] + red[3][c + 128]) * sc;   // sums of g = dy*scale
+    const float Sg = Sg0 * sc, Sgx = Sgx0 * sc;                 // sums of g = dy*scale
     const float dvar = -0.5f * Sgx / (var * sd);
     const float dmu = -Sg / sd + dvar * 2.f * cpad * mean / fn;
     float* db = dx + base;
-    for (int r = hf; r < n; r += 2) {
+    for (int r = rg; r < n; r += 8) {
         const float d = xb[(size_t)r * RN_D + c] - mean;
         db[(size_t)r * RN_D + c] = gb[(size_t)r * RN_D + c] * sc / sd + dvar * 2.f * d / fn + dmu / fn;
     }
-    if (hf == 0) {
-        part[(size_t)b * 256 + c] = (red[3][c] + red[3][c + 128]) / sd;
-        part[(size_t)b * 256 + 128 + c] = red[2][c] + red[2][c + 128];
+    if (rg == 0) {
+        part[(size_t)b * 256 + c] = Sgx0 / sd;
+        part[(size_t)b * 256 + 128 + c] = Sg0;
     }
 }
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
               float* dshift, const TScratch& sc, hipStream_t s) {
     // per-RNA partials of (dscale, dshift), added in RNA order (needs B * 256 floats of scratch)
-    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, sc.p);
+    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B, 4), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, sc.p);
     if (dscale) reduce_parts(sc.p, pk.B, 256, 128, 128, dscale, 128, s);
     if (dshift) reduce_parts(sc.p + 128, pk.B, 256, 128, 128, dshift, 128, s);
 }
@@ -707,9 +734,11 @@ __device__ __forceinline__ tu32x4 frag_row(const float* __restrict__ src, int ld
     const float* p = src + (size_t)(ok ? row : 0) * ld + k0;
     const tf32x4 a = *reinterpret_cast<const tf32x4*>(p), b = *reinterpret_cast<const tf32x4*>(p + 4);
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    if (act) {
+    if (act) {                                  // (ld_idx and k0 are multiples of 8)
+        float dm[8];
+        drop8(dr, drop_key(dr, site), (unsigned)(((unsigned long long)row * ld_idx + k0) >> 3), dm);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * drop_mul(dr, site, (unsigned long long)row * ld_idx + k0 + j);
+        for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * dm[j];
     }
     if (!ok) {
 #pragma unroll
@@ -736,33 +765,33 @@ __device__ __forceinline__ tu32x4 frag_col(const float* __restrict__ src, int ld
 // ---- NT / NN: Y[m][n] (+)= sum_k A[m][k] * B[k][n]  (+ bias[n]) (* gelu'(pre[m][n]) * mask)
 //   A = X rows (k along the row; optional GELU+dropout prologue);  B_NT: B[k][n] = W[n][k] (W row-major [N][K]);
 //   B_NN: B[k][n] = W[k][n] (W row-major [K][N]).  Wave tile 64 rows x 128 columns, workgroup = 4 waves = 256 rows.
-template <bool B_ROWS>      // true: NT (B fragment from rows of W[N][K]); false: NN (B fragment from columns of W[K][N])
+template <bool B_ROWS, int MT>      // B_ROWS true: NT (B fragment from rows of W[N][K]); false: NN (B fragment from columns of W[K][N]); MT row tiles of 32 per wave
 __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict__ X, int ldx, int K, const float* __restrict__ W, int ldw,
         const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
         int ld_epi, TDrop dr, unsigned site) {
     const int R = nrows(rows);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * 256 + wave * 64;
-    if (blockIdx.x * 256 >= R) return;
+    const int m0 = blockIdx.x * (128 * MT) + wave * (32 * MT);
+    if (blockIdx.x * (128 * MT) >= R) return;
     const int n0 = blockIdx.y * 128;
-    tf32x16 acc[2][4];
+    tf32x16 acc[MT][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16) {
-        tu32x4 af[2], bf[4];
+        tu32x4 af[MT], bf[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) af[a] = frag_row(X, ldx, m0 + 32 * a + r, R, k0 + 8 * h, actA != 0, dr, site, K);
+        for (int a = 0; a < MT; ++a) af[a] = frag_row(X, ldx, m0 + 32 * a + r, R, k0 + 8 * h, actA != 0, dr, site, K);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (B_ROWS) bf[b] = frag_row(W, ldw, n0 + 32 * b + r, N, k0 + 8 * h, false, dr, 0u, 0);
             else bf[b] = frag_col(W, ldw, k0 + 8 * h, K, n0 + 32 * b + r, N, false, dr, 0u, 0);
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
     }
@@ -772,7 +801,7 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
         const bool colok = col < N;
         const float bv = (bias && colok) ? bias[col] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -837,8 +866,10 @@ __global__ void __launch_bounds__(256, 1) k_mm128(TRows rows, const float* __res
             float v[8] = {raw[2 * ks][0], raw[2 * ks][1], raw[2 * ks][2], raw[2 * ks][3],
                           raw[2 * ks + 1][0], raw[2 * ks + 1][1], raw[2 * ks + 1][2], raw[2 * ks + 1][3]};
             if (actA) {
+                float dm[8];
+                drop8(dr, drop_key(dr, site), (unsigned)row * 16u + 2 * ks + h, dm);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * drop_mul(dr, site, (unsigned long long)row * 128 + 16 * ks + 8 * h + j);
+                for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]) * dm[j];
             }
             if (row >= R) {
 #pragma unroll
@@ -899,9 +930,17 @@ bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* 
                            actA ? 1 : 0, (const float*)nullptr, dr, site);
         return true;
     }
-    dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
-    hipLaunchKernelGGL(k_mm<true>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0,
-                       (const float*)nullptr, 0, dr, site);
+    // 64-row wave tiles reuse the B fragments twice; with few rows (node tensors) 32-row tiles fill more of the chip
+    const bool small = (long long)((rows.maxrows + 255) / 256) * ((N + 127) / 128) < 2 * rn_num_cus();
+    if (small) {
+        dim3 grid((rows.maxrows + 127) / 128, (N + 127) / 128);
+        hipLaunchKernelGGL((k_mm<true, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0,
+                           (const float*)nullptr, 0, dr, site);
+    } else {
+        dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
+        hipLaunchKernelGGL((k_mm<true, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0,
+                           (const float*)nullptr, 0, dr, site);
+    }
     return true;
 }
 // Y = [beta Y] + (X . W) [* gelu'(pre) * mask]    (W [K][N] row-major; backward dX = dY . W with W = nn.Linear.weight [out][in])
@@ -913,8 +952,14 @@ bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* 
                            epi_pre, dr, site);
         return true;
     }
-    dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
-    hipLaunchKernelGGL(k_mm<false>, grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, 0, epi_pre, ld_epi, dr, site);
+    const bool small = (long long)((rows.maxrows + 255) / 256) * ((N + 127) / 128) < 2 * rn_num_cus();
+    if (small) {
+        dim3 grid((rows.maxrows + 127) / 128, (N + 127) / 128);
+        hipLaunchKernelGGL((k_mm<false, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, 0, epi_pre, ld_epi, dr, site);
+    } else {
+        dim3 grid((rows.maxrows + 255) / 256, (N + 127) / 128);
+        hipLaunchKernelGGL((k_mm<false, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, 0, epi_pre, ld_epi, dr, site);
+    }
     return true;
 }
 
@@ -936,7 +981,7 @@ __device__ __forceinline__ tu32x4 tr_frag(const unsigned short* tile, int row0, 
     return tu32x4{l2[0], l2[1], h2[0], h2[1]};
 }
 __global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restrict__ A, int lda, int M, const float* __restrict__ B,
-        int ldb, int K, float* __restrict__ part, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+        int ldb, int K, float* __restrict__ part, size_t pstride, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
     __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
     __shared__ float cs_red[8][128];
     const int R = nrows(rows);
@@ -1014,10 +1059,10 @@ __global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restri
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) t += cs_red[g][tid];
-            cs_part[(size_t)blockIdx.z * M + n0 + tid] = t;
+            cs_part[(size_t)blockIdx.z * pstride + n0 + tid] = t;
         }
     }
-    float* dst = part + (size_t)blockIdx.z * M * K;
+    float* dst = part + (size_t)blockIdx.z * pstride;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1035,7 +1080,7 @@ void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* 
     const size_t mk = (size_t)M * K;
     const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
     long long cap = (long long)((sc.floats - (size_t)520 * M) / mk) - 16;   // behind the partials: 16 * mk floats for the two-level reduction, 520 * M for the column sums
-    int splits = (rows.maxrows + 1023) / 1024;                // >= 1024 rows (16 tiles) per workgroup
+    int splits = (rows.maxrows + 255) / 256;                  // >= 256 rows (4 tiles) per workgroup
     const int want = (2 * rn_num_cus() + tiles - 1) / tiles;  // enough workgroups for the chip
     if (splits > want) splits = want;
     if (splits > cap) splits = (int)cap;
@@ -1047,12 +1092,13 @@ void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* 
         if (dbias) t_colsum(rows, A, lda, M, dbias, sc, s);
         return;
     }
-    float* tmp = sc.p + (size_t)splits * mk;                  // [16][mk] second-level buffer, then [splits + 16][M] column sums
-    float* cs = dbias ? tmp + 16 * mk : nullptr;
+    // partial of split z: [M*K tile][M column sums (with dbias)]: one ordered reduction adds both into dW / dbias
+    const size_t pstride = mk + (dbias ? (size_t)M : 0);
+    float* tmp = sc.p + (size_t)splits * pstride;             // [16][pstride] second-level buffer
     dim3 grid((M + 127) / 128, (K + 127) / 128, splits);
-    hipLaunchKernelGGL(k_mm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, rps, actB ? 1 : 0, dr, site, cs);
-    reduce_parts(sc.p, splits, mk, (int)mk, K, dW, ldw, s, tmp);
-    if (dbias) reduce_parts(cs, splits, (size_t)M, M, M, dbias, M, s, cs + (size_t)splits * M);
+    hipLaunchKernelGGL(k_mm_tn, grid, dim3(256), 0, s, rows, A, lda, M, B, ldb, K, sc.p, pstride, rps, actB ? 1 : 0, dr, site,
+                       dbias ? sc.p + mk : (float*)nullptr);
+    reduce_parts(sc.p, splits, pstride, (int)pstride, K, dW, ldw, s, tmp, (int)mk, dbias);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1102,10 +1148,15 @@ struct EmmArgs {
 // is the A operand (its rows permuted so that a lane's 16 accumulator registers of a 32-channel block are two runs of 8 CONSECUTIVE
 // channels) and the 32 edge rows of a tile are the B operand (lane (r, h) = 8 consecutive k of row r: one 16-byte bf16 load).  Every
 // lane then owns 64 channels of ITS edge row: the epilogue's loads / stores (old Y, taped pre-activation, P / Q rows, residual input,
-// outputs) are all 16-byte row-contiguous accesses, and row-wise data (neighbour index, validity) is per lane.  The whole weight lives in
-// registers (128 VGPRs of A fragments, one wave per SIMD), a wave streams 32-row tiles past it with the next tile's X in flight.
-template <bool B_ROWS, typename TX>
-__global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
+// outputs) are all 16-byte row-contiguous accesses, and row-wise data (neighbour index, validity) is per lane.
+// The kernel is a stream (256 B in, 256 - 768 B out / side inputs per row) with ~40 VALU operations per element when an activation
+// or its derivative is fused: two waves per SIMD (weight fragments from a 32 KiB LDS image instead of 128 registers) so that one
+// wave's loads and VALU run under the other's MFMAs, the next tile's X and THIS tile's epilogue operands are requested before the MFMA
+// block, and every load of the epilogue sits in registers before the first store (stores would otherwise fence the later loads: the
+// compiler cannot prove that Y does not alias them).
+// EP: 0 none, 1 + P[row / k] + Q[nbr[row]], 2 * gelu'(pre) * mask, 3 + old Y;  ACT: X' = drop(gelu(X));  RES: second output res_in + drop(gelu(v))
+template <bool B_ROWS, typename TX, int EP, bool ACT, bool RES>
+__global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short img[32 * 64 * 8];      // [ks][cb][lane][8] bf16 A fragments
     __shared__ __attribute__((aligned(16))) float lds_bias[128];
     const int R = nrows(a.rows);
@@ -1122,18 +1173,17 @@ __global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
     }
     if (tid < 128) lds_bias[tid] = a.bias ? a.bias[tid] : 0.f;
     __syncthreads();
-    tu32x4 wf[8][4];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) wf[ks][cb] = reinterpret_cast<const tu32x4*>(img)[(ks * 4 + cb) * 64 + lane];
+    const tu32x4* wimg = reinterpret_cast<const tu32x4*>(img) + lane;
     const int ntiles = (R + 31) / 32;
     const int tstride = gridDim.x * 4;
+    const unsigned key1 = drop_key(a.dr, a.site), key2 = drop_key(a.dr, a.f.site2);
     constexpr bool XB = sizeof(TX) == 2;
-    tu32x4 rawb[8];                    // bf16 X: the fragments themselves
+    constexpr bool NEED_J = EP == 1 || RES;
+    tu32x4 rawb[XB ? 8 : 1];           // bf16 X: the fragments themselves
     tf32x4 rawf[XB ? 1 : 16];          // f32 X
     int jn = -1;                       // neighbour of the prefetched tile's row
     const TX* __restrict__ X = reinterpret_cast<const TX*>(a.X);
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
     auto load_raw = [&](int t) {
         const int row = min(32 * t + r, R - 1);
         const TX* p = X + (size_t)row * a.ldx + 8 * h;
@@ -1147,7 +1197,7 @@ __global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
                 rawf[2 * ks + 1] = *reinterpret_cast<const tf32x4*>(p + 16 * ks + 4);
             }
         }
-        if (a.f.nbr) jn = a.f.nbr[row];
+        if constexpr (NEED_J) jn = a.f.nbr[row];
     };
     int t = blockIdx.x * 4 + wave;
     if (t < ntiles) load_raw(t);
@@ -1156,10 +1206,31 @@ __global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
         const bool rok = row < R;
         const int rowc = rok ? row : R - 1;
         const int j = jn;
+        // ---- epilogue operands of this tile, group u = channels 16u + 8h .. +7 of this lane's row
+        tu32x4 e0[EP ? 8 : 1], e1[(EP == 1 || RES) ? 8 : 1];      // e0: P row | taped pre-activation | old Y;  e1: Q row | residual input
+        {
+            const size_t ro = (size_t)rowc * 128 + 8 * h;
+            if constexpr (EP == 1) {
+                const tb16* prow = a.f.P + (size_t)(rowc / a.f.k) * 128 + 8 * h;
+                const tb16* qrow = a.f.Q + (size_t)(j < 0 ? a.f.zero_row : (j > a.f.zero_row ? a.f.zero_row : j)) * 128 + 8 * h;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { e0[u] = *reinterpret_cast<const tu32x4*>(prow + 16 * u); e1[u] = *reinterpret_cast<const tu32x4*>(qrow + 16 * u); }
+            } else if constexpr (EP == 2) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e0[u] = *reinterpret_cast<const tu32x4*>(a.epi_pre + ro + 16 * u);
+            } else if constexpr (EP == 3) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e0[u] = *reinterpret_cast<const tu32x4*>(a.Y + ro + 16 * u);
+            }
+            if constexpr (RES && EP != 1) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e1[u] = *reinterpret_cast<const tu32x4*>(a.f.res_in + ro + 16 * u);
+            }
+        }
         tu32x4 xf[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            if (XB && !a.actA) { xf[ks] = rawb[ks]; }
+            if constexpr (XB && !ACT) { xf[ks] = rawb[ks]; }
             else {
                 float v[8];
                 if constexpr (XB) unpack8(rawb[ks], v);
@@ -1167,13 +1238,15 @@ __global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { v[q] = rawf[2 * ks][q]; v[4 + q] = rawf[2 * ks + 1][q]; }
                 }
-                if (a.actA) {
+                if constexpr (ACT) {
+                    float dm[8];
+                    drop8(a.dr, key1, (unsigned)row * 16u + 2 * ks + h, dm);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * drop_mul(a.dr, a.site, (unsigned long long)row * 128 + 16 * ks + 8 * h + q);
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * dm[q];
                 }
                 xf[ks] = tpack8(v);
             }
-            if (!rok) xf[ks] = tu32x4{0u, 0u, 0u, 0u};
+            if (!rok) xf[ks] = z4;
         }
         if (t + tstride < ntiles) load_raw(t + tstride);
         tf32x16 acc[4];
@@ -1181,59 +1254,77 @@ __global__ void __launch_bounds__(256, 1) k_emm128(EmmArgs a) {
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+        // weight fragments from LDS, one k-step ahead of the MFMAs that use them (pinned: hoisting all 32 reads costs 128 registers)
+        tu32x4 wa[4], wb[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int cb = 0; cb < 4; ++cb) wa[cb] = wimg[cb * 64];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wf[ks][cb], xf[ks], acc[cb]);
-        // ---- epilogue: this lane's row, channels c0 .. c0+7 and c0+16 .. c0+23 of every 32-channel block
-        const float* prow = nullptr;
-        const float* qrow = nullptr;
-        if (a.has_pq) {
-            prow = a.f.pq + (size_t)(rowc / a.f.k) * 256;
-            qrow = a.f.pq + (size_t)(j < 0 ? a.f.zero_row : (j > a.f.zero_row ? a.f.zero_row : j)) * 256 + 128;
+        for (int ks = 0; ks < 8; ks += 2) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) wb[cb] = wimg[((ks + 1) * 4 + cb) * 64];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wa[cb], xf[ks], acc[cb]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 8) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[cb] = wimg[((ks + 2) * 4 + cb) * 64];
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wb[cb], xf[ks + 1], acc[cb]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- epilogue in two halves of 64 channels: compute, then store (all loads are already in registers)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const int c0 = 32 * cb + 8 * h;
-            float v[16];
+        for (int half = 0; half < 2; ++half) {
+            tu32x4 yo[4], ro2[RES ? 4 : 1];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[cb][i];
+            for (int uu = 0; uu < 4; ++uu) {
+                const int u = 4 * half + uu, cb = u >> 1, g = u & 1, c = 16 * u + 8 * h;
+                float v[8];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int c = c0 + 16 * g;
+                for (int q = 0; q < 8; ++q) v[q] = acc[cb][8 * g + q];
                 const tf32x4 b0 = *reinterpret_cast<const tf32x4*>(lds_bias + c), b1 = *reinterpret_cast<const tf32x4*>(lds_bias + c + 4);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[8 * g + q] += b0[q]; v[8 * g + 4 + q] += b1[q]; }
-                if (a.has_pq) {
-                    const tf32x4 p0 = *reinterpret_cast<const tf32x4*>(prow + c), p1 = *reinterpret_cast<const tf32x4*>(prow + c + 4);
-                    const tf32x4 q0 = *reinterpret_cast<const tf32x4*>(qrow + c), q1 = *reinterpret_cast<const tf32x4*>(qrow + c + 4);
+                for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+                if constexpr (EP == 1) {
+                    float pv[8], qv[8];
+                    unpack8(e0[u], pv); unpack8(e1[u], qv);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[8 * g + q] += p0[q] + q0[q]; v[8 * g + 4 + q] += p1[q] + q1[q]; }
+                    for (int q = 0; q < 8; ++q) v[q] += pv[q] + qv[q];
+                } else if constexpr (EP == 2) {
+                    float pr[8], dm[8];
+                    unpack8(e0[u], pr);
+                    drop8(a.dr, key1, (unsigned)row * 16u + (c >> 3), dm);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= gelu_d_fast(pr[q]) * dm[q];
+                } else if constexpr (EP == 3) {
+                    float old[8];
+                    unpack8(e0[u], old);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += old[q];
                 }
-                if (a.epi_pre) {
-                    float pr[8];
-                    unpack8(*reinterpret_cast<const tu32x4*>(a.epi_pre + (size_t)rowc * 128 + c), pr);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[8 * g + q] *= gelu_d_fast(pr[q]) * drop_mul(a.dr, a.site, (unsigned long long)row * 128 + c + q);
-                }
-                if (a.beta) {
-                    float yo[8];
-                    unpack8(*reinterpret_cast<const tu32x4*>(a.Y + (size_t)rowc * 128 + c), yo);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[8 * g + q] += yo[q];
-                }
-                float o[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) o[q] = v[8 * g + q];
-                if (rok) *reinterpret_cast<tu32x4*>(a.Y + (size_t)row * 128 + c) = tpack8(o);
-                if (a.has_res) {
+                yo[uu] = tpack8(v);
+                if constexpr (RES) {
                     float ei[8];
-                    unpack8(*reinterpret_cast<const tu32x4*>(a.f.res_in + (size_t)rowc * 128 + c), ei);
+                    if constexpr (EP == 1) unpack8(*reinterpret_cast<const tu32x4*>(a.f.res_in + (size_t)rowc * 128 + c), ei);   // (depth-1 MLPs only)
+                    else unpack8(e1[u], ei);
                     if (j >= 0) {
+                        float dm[8];
+                        drop8(a.dr, key2, (unsigned)row * 16u + (c >> 3), dm);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) ei[q] += gelu_fast(o[q]) * drop_mul(a.dr, a.f.site2, (unsigned long long)row * 128 + c + q);
+                        for (int q = 0; q < 8; ++q) ei[q] += gelu_fast(v[q]) * dm[q];
                     }
-                    if (rok) *reinterpret_cast<tu32x4*>(a.f.res_out + (size_t)row * 128 + c) = tpack8(ei);
+                    ro2[uu] = tpack8(ei);
+                }
+            }
+            if (rok) {
+                tb16* yrow = a.Y + (size_t)row * 128 + 64 * half + 8 * h;
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu) *reinterpret_cast<tu32x4*>(yrow + 16 * uu) = yo[uu];
+                if constexpr (RES) {
+                    tb16* rrow = a.f.res_out + (size_t)row * 128 + 64 * half + 8 * h;
+#pragma unroll
+                    for (int uu = 0; uu < 4; ++uu) *reinterpret_cast<tu32x4*>(rrow + 16 * uu) = ro2[uu];
                 }
             }
         }
@@ -1244,23 +1335,29 @@ void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
     EmmArgs a;
     a.rows = rows; a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y; a.beta = beta; a.actA = actA ? 1 : 0;
     a.epi_pre = epi_pre; a.dr = dr; a.site = site;
-    if (fuse) a.f = *fuse; else a.f = EFuse{nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
-    a.has_pq = a.f.pq != nullptr; a.has_res = a.f.res_out != nullptr;
-    const dim3 grid(mm128_grid(rows));
-    if (w_rows) {
-        if (x_bf16) hipLaunchKernelGGL((k_emm128<true, tb16>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_emm128<true, float>), grid, dim3(256), 0, s, a);
-    } else {
-        if (x_bf16) hipLaunchKernelGGL((k_emm128<false, tb16>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_emm128<false, float>), grid, dim3(256), 0, s, a);
-    }
+    if (fuse) a.f = *fuse; else a.f = EFuse{nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
+    a.has_pq = a.f.P != nullptr; a.has_res = a.f.res_out != nullptr;
+    int g = (rows.maxrows + 127) / 128;                      // 4 waves x one 32-row tile each
+    const int cap = 2 * rn_num_cus();                        // two workgroups per CU (two waves per SIMD)
+    const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
+    const int ep = a.has_pq ? 1 : (epi_pre ? 2 : (beta ? 3 : 0));
+#define EMM_GO(BR, TXT, EPV, ACTV, RESV) hipLaunchKernelGGL((k_emm128<BR, TXT, EPV, ACTV, RESV>), grid, dim3(256), 0, s, a)
+    if (!x_bf16 && w_rows && ep == 0 && !actA && !a.has_res) EMM_GO(true, float, 0, false, false);                 // node rows -> bf16 P / Q tables
+    else if (x_bf16 && w_rows && ep == 1 && !actA && !a.has_res) EMM_GO(true, tb16, 1, false, false);             // first Linear + P + Q
+    else if (x_bf16 && w_rows && ep == 1 && !actA && a.has_res) EMM_GO(true, tb16, 1, false, true);               // ... of a depth-1 edge update
+    else if (x_bf16 && w_rows && ep == 0 && actA && !a.has_res) EMM_GO(true, tb16, 0, true, false);               // second Linear (message)
+    else if (x_bf16 && w_rows && ep == 0 && actA && a.has_res) EMM_GO(true, tb16, 0, true, true);                 // second Linear + edge update
+    else if (x_bf16 && !w_rows && ep == 2 && !actA && !a.has_res) EMM_GO(false, tb16, 2, false, false);           // d pre1 = (d pre2 . W2) gelu' mask
+    else if (x_bf16 && !w_rows && ep == 3 && !actA && !a.has_res) EMM_GO(false, tb16, 3, false, false);           // dE += d pre1 . Wc
+    else { fprintf(stderr, "te_gemm: combination not instantiated\n"); abort(); }
+#undef EMM_GO
 }
 
 // ---- TN with bf16 operands: dW[n][kk] += sum_m A[m][n] actB(B[m][kk]), M = K = 128.  Same scheme as k_mm_tn (64-row tiles row-major
 // in LDS, transposed fragment reads, row range split over blockIdx.z, ordered reduction of the partial tiles); the staging is a straight
 // 16-byte copy unless the activation prologue is on.
 __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restrict__ A, const tb16* __restrict__ B, float* __restrict__ part,
-        int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+        size_t pstride, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
     __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
     __shared__ float cs_red[16][128];
     const int R = nrows(rows);
@@ -1268,25 +1365,18 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
     const int wr = wave >> 1, wc = wave & 1;
     const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
     const int ch = tid & 15, rg = tid >> 4;                   // 16-byte chunk ch of rows rg, rg+16, rg+32, rg+48
-    tu32x4 ra[4], rb[4];
+    const unsigned key = drop_key(dr, site);
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto load_tile = [&](int m0) {
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    // raw tile loads, TWO tiles ahead of the MFMAs (a workgroup alone cannot cover the HBM latency with one); the activation
+    // prologue runs when the tile is moved to LDS
+    auto load_tile = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + rg + 16 * i;
-            const bool ok = m < p_end;
-            const int mc = ok ? m : (R > 0 ? R - 1 : 0);
-            tu32x4 va = *reinterpret_cast<const tu32x4*>(A + (size_t)mc * 128 + 8 * ch);
-            tu32x4 vb = *reinterpret_cast<const tu32x4*>(B + (size_t)mc * 128 + 8 * ch);
-            if (actB) {
-                float v[8];
-                unpack8(vb, v);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * drop_mul(dr, site, (unsigned long long)m * 128 + 8 * ch + q);
-                vb = tpack8(v);
-            }
-            if (!ok) { va = tu32x4{0u, 0u, 0u, 0u}; vb = va; }
-            ra[i] = va; rb[i] = vb;
+            const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+            xa[i] = *reinterpret_cast<const tu32x4*>(A + (size_t)mc * 128 + 8 * ch);
+            xb[i] = *reinterpret_cast<const tu32x4*>(B + (size_t)mc * 128 + 8 * ch);
         }
     };
     tf32x16 acc[2][2];
@@ -1296,25 +1386,34 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    if (p_begin < p_end) load_tile(p_begin);
-    for (int m0 = p_begin; m0 < p_end; m0 += 64) {
-        __syncthreads();
+    auto stage = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
+        __syncthreads();                                      // the previous tile's fragment reads are done
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = ra[i];
-            *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = rb[i];
-        }
-        if (cs_part) {
+            const int m = m0 + rg + 16 * i;
+            const bool ok = m < p_end;
+            tu32x4 va = ok ? xa[i] : z4, vb = xb[i];
+            if (actB) {
+                float v[8], dm[8];
+                unpack8(vb, v);
+                drop8(dr, key, (unsigned)m * 16u + ch, dm);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * dm[q];
+                vb = tpack8(v);
+            }
+            if (!ok) vb = z4;
+            *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = va;
+            *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = vb;
+            if (cs_part) {
                 float v[8];
-                unpack8(ra[i], v);
+                unpack8(va, v);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) csum[q] += v[q];
             }
         }
         __syncthreads();
-        if (m0 + 64 < p_end) load_tile(m0 + 64);
+    };
+    auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             tu32x4 af[2], bf[2];
@@ -1327,8 +1426,23 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
         }
+    };
+    tu32x4 a0[4], b0[4], a1[4], b1[4];
+    int m0 = p_begin;
+    if (m0 < p_end) { load_tile(m0, a0, b0); load_tile(m0 + 64, a1, b1); }
+    while (m0 < p_end) {
+        stage(m0, a0, b0);
+        load_tile(m0 + 128, a0, b0);
+        compute();
+        m0 += 64;
+        if (m0 >= p_end) break;
+        stage(m0, a1, b1);
+        load_tile(m0 + 128, a1, b1);
+        compute();
+        m0 += 64;
     }
     if (cs_part) {                                            // rows rg, rg+16, ... were summed per thread: fold the 16 row groups in order
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) cs_red[rg][8 * ch + q] = csum[q];
         __syncthreads();
@@ -1336,10 +1450,10 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) t += cs_red[g][tid];
-            cs_part[(size_t)blockIdx.z * 128 + tid] = t;
+            cs_part[(size_t)blockIdx.z * pstride + tid] = t;
         }
     }
-    float* dst = part + (size_t)blockIdx.z * 128 * 128;
+    float* dst = part + (size_t)blockIdx.z * pstride;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1360,11 +1474,11 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
     if (splits > 500) splits = 500;
     if (splits < 1) splits = 1;
     const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
-    float* tmp = sc.p + (size_t)splits * mk;
-    float* cs = dbias ? tmp + 16 * mk : nullptr;
-    hipLaunchKernelGGL(k_emm_tn, dim3(1, 1, splits), dim3(256), 0, s, rows, A, B, sc.p, rps, actB ? 1 : 0, dr, site, cs);
-    reduce_parts(sc.p, splits, mk, (int)mk, 128, dW, ldw, s, tmp);
-    if (dbias) reduce_parts(cs, splits, (size_t)128, 128, 128, dbias, 128, s, cs + (size_t)splits * 128);
+    const size_t pstride = mk + (dbias ? 128 : 0);
+    float* tmp = sc.p + (size_t)splits * pstride;
+    hipLaunchKernelGGL(k_emm_tn, dim3(1, 1, splits), dim3(256), 0, s, rows, A, B, sc.p, pstride, rps, actB ? 1 : 0, dr, site,
+                       dbias ? sc.p + mk : (float*)nullptr);
+    reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw, s, tmp, (int)mk, dbias);
 }
 
 // ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
@@ -1373,14 +1487,17 @@ __global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
     const int c = 2 * (threadIdx.x & 63);
+    const unsigned key = drop_key(dr, site);
     float s0 = 0.f, s1 = 0.f;
     int cnt = 0;
     for (int sl = 0; sl < k; ++sl) {
         const size_t er = (size_t)p * k + sl;
         if (nbr[er] >= 0) {
             const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
-            s0 += gelu_fast(tbf_lo(w)) * drop_mul(dr, site, er * RN_D + c);
-            s1 += gelu_fast(tbf_hi(w)) * drop_mul(dr, site, er * RN_D + c + 1);
+            float m0, m1;
+            drop_pair(dr, key, (unsigned)er * 64u + (c >> 1), m0, m1);
+            s0 += gelu_fast(tbf_lo(w)) * m0;
+            s1 += gelu_fast(tbf_hi(w)) * m1;
             ++cnt;
         }
     }
@@ -1402,8 +1519,9 @@ __global__ void __launch_bounds__(256) k_eseg_mean_bwd(PackInfo pk, int k, const
         unsigned o = 0u;
         if (nbr[er] >= 0) {
             const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
-            o = tpack2(g[0] * inv * gelu_d_fast(tbf_lo(w)) * drop_mul(dr, site, er * RN_D + c),
-                       g[1] * inv * gelu_d_fast(tbf_hi(w)) * drop_mul(dr, site, er * RN_D + c + 1));
+            float m0, m1;
+            drop_pair(dr, drop_key(dr, site), (unsigned)er * 64u + (c >> 1), m0, m1);
+            o = tpack2(g[0] * inv * gelu_d_fast(tbf_lo(w)) * m0, g[1] * inv * gelu_d_fast(tbf_hi(w)) * m1);
         }
         *reinterpret_cast<unsigned*>(dpre2 + er * RN_D + c) = o;
     }
@@ -1427,8 +1545,10 @@ __global__ void k_eelem(PackInfo pk, int k, const int* __restrict__ nbr, int mod
             float d[8], pr[8];
             unpack8(reinterpret_cast<const tu32x4*>(de)[id], d);
             unpack8(reinterpret_cast<const tu32x4*>(pre2)[id], pr);
+            float dm[8];
+            drop8(dr, drop_key(dr, site), (unsigned)id, dm);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] *= gelu_d_fast(pr[q]) * drop_mul(dr, site, id * 8 + q);
+            for (int q = 0; q < 8; ++q) d[q] *= gelu_d_fast(pr[q]) * dm[q];
             o = tpack8(d);
         }
         *xp = o;
@@ -1441,23 +1561,38 @@ void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, 
 void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s) {
     hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, nullptr, x, TDrop{0, 0, 1.f}, 0u);
 }
+// one wave per residue: lane = (row group g of 4, 16-byte chunk c16 of the 256-byte row); the 4 groups are folded with fixed-order shuffles
 __global__ void __launch_bounds__(256) k_epq_bwd(PackInfo pk, int k, const tb16* __restrict__ dpre1, const int* __restrict__ start,
                                                  const int* __restrict__ list, float* __restrict__ dpq) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
-    const int c = 2 * (threadIdx.x & 63);
-    float s0 = 0.f, s1 = 0.f;
-    for (int sl = 0; sl < k; ++sl) {
-        const unsigned w = *reinterpret_cast<const unsigned*>(dpre1 + ((size_t)p * k + sl) * RN_D + c);
-        s0 += tbf_lo(w); s1 += tbf_hi(w);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = 8 * (lane & 15);
+    float sp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sl = g; sl < k; sl += 4) {
+        float v[8];
+        unpack8(*reinterpret_cast<const tu32x4*>(dpre1 + ((size_t)p * k + sl) * RN_D + c), v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sp[q] += v[q];
     }
-    *reinterpret_cast<tf32x2*>(dpq + (size_t)p * 256 + c) = tf32x2{s0, s1};
-    float q0 = 0.f, q1 = 0.f;
-    for (int t = start[p]; t < start[p + 1]; ++t) {
-        const unsigned w = *reinterpret_cast<const unsigned*>(dpre1 + (size_t)list[t] * RN_D + c);
-        q0 += tbf_lo(w); q1 += tbf_hi(w);
+    const int t1 = start[p + 1];
+    for (int t = start[p] + g; t < t1; t += 4) {
+        float v[8];
+        unpack8(*reinterpret_cast<const tu32x4*>(dpre1 + (size_t)list[t] * RN_D + c), v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sq[q] += v[q];
     }
-    *reinterpret_cast<tf32x2*>(dpq + (size_t)p * 256 + 128 + c) = tf32x2{q0, q1};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sp[q] += __shfl_xor(sp[q], 16, 64); sp[q] += __shfl_xor(sp[q], 32, 64);
+        sq[q] += __shfl_xor(sq[q], 16, 64); sq[q] += __shfl_xor(sq[q], 32, 64);
+    }
+    if (g == 0) {
+        float* o = dpq + (size_t)p * 256 + c;
+        *reinterpret_cast<tf32x4*>(o) = tf32x4{sp[0], sp[1], sp[2], sp[3]};
+        *reinterpret_cast<tf32x4*>(o + 4) = tf32x4{sp[4], sp[5], sp[6], sp[7]};
+        *reinterpret_cast<tf32x4*>(o + 128) = tf32x4{sq[0], sq[1], sq[2], sq[3]};
+        *reinterpret_cast<tf32x4*>(o + 132) = tf32x4{sq[4], sq[5], sq[6], sq[7]};
+    }
 }
 void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* start, const int* list, float* dpq, hipStream_t s) {
     hipLaunchKernelGGL(k_epq_bwd, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, dpre1, start, list, dpq);
@@ -1466,7 +1601,9 @@ __global__ void k_egelu_fwd_out(TRows rows, const float* __restrict__ x, tb16* _
     const size_t n = (size_t)nrows(rows) * D / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const tf32x2 v = reinterpret_cast<const tf32x2*>(x)[i];
-        reinterpret_cast<unsigned*>(y)[i] = tpack2(gelu_f(v[0]) * drop_mul(dr, site, 2 * i), gelu_f(v[1]) * drop_mul(dr, site, 2 * i + 1));
+        float m0, m1;
+        drop_pair(dr, drop_key(dr, site), (unsigned)i, m0, m1);
+        reinterpret_cast<unsigned*>(y)[i] = tpack2(gelu_f(v[0]) * m0, gelu_f(v[1]) * m1);
     }
 }
 __global__ void k_egelu_bwd_in(TRows rows, const tb16* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, int D, TDrop dr, unsigned site) {
@@ -1474,7 +1611,9 @@ __global__ void k_egelu_bwd_in(TRows rows, const tb16* __restrict__ dy, const fl
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const unsigned w = reinterpret_cast<const unsigned*>(dy)[i];
         const tf32x2 p = reinterpret_cast<const tf32x2*>(pre)[i];
-        reinterpret_cast<tf32x2*>(dx)[i] = tf32x2{tbf_lo(w) * gelu_d(p[0]) * drop_mul(dr, site, 2 * i), tbf_hi(w) * gelu_d(p[1]) * drop_mul(dr, site, 2 * i + 1)};
+        float m0, m1;
+        drop_pair(dr, drop_key(dr, site), (unsigned)i, m0, m1);
+        reinterpret_cast<tf32x2*>(dx)[i] = tf32x2{tbf_lo(w) * gelu_d(p[0]) * m0, tbf_hi(w) * gelu_d(p[1]) * m1};
     }
 }
 void te_gelu_fwd_out(const TRows& rows, const float* x, tb16* y, int D, const TDrop& dr, unsigned site, hipStream_t s) {

@@ -1,10 +1,10 @@
 #!/bin/bash
-# per-kernel time of training steps under rocprofv3 --kernel-trace.  usage: tools/kstats_train.sh <outdir> [B] [precision] [steps]
+# per-kernel time of training steps under rocprofv3 --kernel-trace.  usage: tools/kstats_train.sh <outdir> [B] [precision] [steps] [lo] [hi]
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$1; shift; mkdir -p $OUT
 python3 $ROOT/__graft_entry__.py || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/train_probe.py "${1:-64}" "${2:-bf16}" "${3:-3}" > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/tools/train_probe.py "${1:-64}" "${2:-bf16}" "${3:-3}" "${4:-100}" "${5:-140}" > $OUT/run.log 2>&1
 tail -1 $OUT/run.log
 python3 - <<PY
 import csv, glob
