@@ -51,7 +51,7 @@ void t_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg
 void t_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const float* de, const float* pre2, float* dpre2,
                     const TDrop& dr, unsigned site, hipStream_t s);
 // reverse adjacency (deg/start/fill: [Nmax+1] ints, list: [Nmax*k] ints) and the gather-form backward of P[i] + Q[j]
-void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, hipStream_t s);
+void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, int* tmp, hipStream_t s);   // tmp: [Nmax*k] ints of scratch
 void t_edge_pq_bwd(const PackInfo& pk, int k, const float* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
               float* dshift, const TScratch& sc, hipStream_t s);

@@ -394,25 +394,28 @@ __global__ void k_rev_fill(PackInfo pk, int k, const int* __restrict__ nbr, int*
         if (j >= 0 && j < pk.Nmax) list[atomicAdd(fill + j, 1)] = (int)e;
     }
 }
-__global__ void k_rev_sort(PackInfo pk, const int* __restrict__ start, int* __restrict__ list) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= pk.cu[pk.B]) return;
-    const int a = start[j], b = start[j + 1];
-    for (int i = a + 1; i < b; ++i) {                                   // insertion sort: in-degrees are small (~k)
-        const int v = list[i];
-        int t = i - 1;
-        while (t >= a && list[t] > v) { list[t + 1] = list[t]; --t; }
-        list[t + 1] = v;
+// The atomics of k_rev_fill leave every list in arrival order.  Final position of an entry = number of smaller entries of its list
+// (lists are short, ~k, and L2-resident): one thread per entry, no serial per-node sort, the result does not depend on the arrival order.
+__global__ void k_rev_rank(PackInfo pk, const int* __restrict__ nbr, const int* __restrict__ start, const int* __restrict__ unsorted,
+                           int* __restrict__ list) {
+    const int total = start[pk.cu[pk.B]];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int er = unsorted[t];
+        const int j = nbr[er];
+        const int a = start[j], b = start[j + 1];
+        int rank = 0;
+        for (int u = a; u < b; ++u) rank += unsorted[u] < er;
+        list[a + rank] = er;
     }
 }
-void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, hipStream_t s) {
+void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, int* tmp, hipStream_t s) {
     (void)hipMemsetAsync(deg, 0, (size_t)pk.Nmax * sizeof(int), s);
     size_t E = (size_t)pk.Nmax * k;
     unsigned g = (unsigned)((E + 255) / 256); if (g > 8192) g = 8192; if (g < 1) g = 1;
     hipLaunchKernelGGL(k_rev_count, dim3(g), dim3(256), 0, s, pk, k, nbr, deg);
     hipLaunchKernelGGL(k_rev_scan, dim3(1), dim3(1024), 0, s, deg, pk.Nmax, start, fill);
-    hipLaunchKernelGGL(k_rev_fill, dim3(g), dim3(256), 0, s, pk, k, nbr, fill, list);
-    hipLaunchKernelGGL(k_rev_sort, dim3((pk.Nmax + 255) / 256), dim3(256), 0, s, pk, start, list);
+    hipLaunchKernelGGL(k_rev_fill, dim3(g), dim3(256), 0, s, pk, k, nbr, fill, tmp);
+    hipLaunchKernelGGL(k_rev_rank, dim3(g), dim3(256), 0, s, pk, nbr, start, tmp, list);
 }
 // dpq[i][0:128] = sum_slots dpre1[(i, slot)]  (P part);  dpq[j][128:256] = sum over incoming edges of j, ascending (Q part)
 __global__ void __launch_bounds__(128) k_edge_pq_bwd(PackInfo pk, int k, const float* __restrict__ dpre1,
