@@ -3,6 +3,7 @@
 #include "../../include/rnampnn_hip.h"
 #include "rnampnn_internal.h"
 #include "kernels_bf16.h"
+#include "kernels_train.h"
 
 #include <cstdarg>
 #include <cstdlib>
@@ -101,6 +102,7 @@ struct rnampnn_ctx {
     uint64_t tape_seed = 0;
     const void* tape_ws = nullptr;
     bool tape_mixed = false;
+    WImageCache* wimg = nullptr;   // prebuilt weight-fragment images of the bf16-mixed trainer (kernels_train.h)
     bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
     // fork / join inside one forward: independent branches of the node stack run on auxiliary streams beside the
     // latency-bound kernels of the caller's stream (k-NN at the start, the small attention kernels at the end)
@@ -328,6 +330,7 @@ extern "C" int rnampnn_destroy(rnampnn_handle h) {
     for (auto& e : h->fj) if (e) (void)hipEventDestroy(e);
     if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
     if (h->der_arena) (void)hipFree(h->der_arena);
+    t_wimg_destroy(h->wimg);
     delete h;
     return RNAMPNN_OK;
 }
@@ -376,6 +379,7 @@ extern "C" int rnampnn_use_weight_arena(rnampnn_handle h, float* arena, void* st
     if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
     h->raw_arena = arena;
     h->raw_external = true;
+    t_wimg_clear(h->wimg);
     if (!h->der_arena) {
         HIP_TRY(hipMalloc((void**)&h->der_arena, h->der_bytes));
         HIP_TRY(hipMemsetAsync(h->der_arena, 0, h->der_bytes, (hipStream_t)stream));

@@ -90,3 +90,12 @@ void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* sta
 void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s);
 void te_gelu_fwd_out(const TRows& rows, const float* x, tb16* y, int D, const TDrop& dr, unsigned site, hipStream_t s);      // y = bf16(drop(gelu(x)))
 void te_gelu_bwd_in(const TRows& rows, const tb16* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site, hipStream_t s);   // dx = dy gelu'(pre) mask
+
+// ---- cache of prebuilt bf16 fragment images of the 128 x 128 weight blocks the weights-resident GEMMs use (kernels_train.hip):
+// bind it for the calling thread, refresh at the start of a training forward (one launch rebuilds every image registered so far).
+struct WImageCache;
+WImageCache* t_wimg_create(int capacity);
+void t_wimg_destroy(WImageCache* c);
+void t_wimg_bind(WImageCache* c);            // null: kernels build their images themselves
+void t_wimg_clear(WImageCache* c);           // the weights moved (new arena)
+void t_wimg_refresh(WImageCache* c, hipStream_t s);

@@ -7,6 +7,7 @@
 // lines cited in kernels_f32.hip.  Dropout: counter-hash masks (TDrop, kernels_train.h); every cross-workgroup sum is an ordered two-stage reduction (no float atomics).
 #include "kernels_train.h"
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 static constexpr float kSEPS = 1.0e-6f;
@@ -765,6 +766,84 @@ __device__ __forceinline__ tu32x4 frag_col(const float* __restrict__ src, int ld
     return tpack8(v);
 }
 
+// ---- bf16 fragment images of 128 x 128 weight blocks (32 KiB: [k-step 8][channel block 4][lane 64][8 bf16]) for the
+// weights-resident GEMM kernels.  layout 0 (k_mm128): B fragments, lane (r, h) = column 32cb + r; layout 1 (k_emm128): A fragments with
+// the row permutation that makes a lane's accumulators two runs of 8 consecutive channels.  A kernel builds its image itself
+// (32 rounds of scattered 4-byte loads per thread, ~10 us of serial latency before the first tile) unless the caller's WImageCache has it:
+// the cache rebuilds ALL registered images in one launch at the start of a training forward.
+struct WImgDesc { const float* W; int ldw; int b_rows; int layout; };
+__device__ __forceinline__ void build_wimage(unsigned short* img, const float* __restrict__ W, int ldw, bool b_rows, int layout, int tid, int nthreads) {
+    for (int e = tid; e < 128 * 64; e += nthreads) {
+        int k, c;
+        float v0, v1;
+        if (b_rows) { c = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)c * ldw + k; v0 = p[0]; v1 = p[1]; }
+        else { k = 2 * (e >> 7); c = e & 127; v0 = W[(size_t)k * ldw + c]; v1 = W[(size_t)(k + 1) * ldw + c]; }
+        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = c >> 5, c5 = c & 31;
+        int rr = c5;
+        if (layout == 1) { const int i = 8 * (c5 >> 4) + (c5 & 7), hq = (c5 >> 3) & 1; rr = (i & 3) + 8 * (i >> 2) + 4 * hq; }
+        *reinterpret_cast<unsigned*>(img + (((ks * 4 + cb) * 64 + hh * 32 + rr) * 8 + j)) = tpack2(v0, v1);
+    }
+}
+__device__ __forceinline__ void stage_wimage(unsigned short* img, const unsigned short* __restrict__ prebuilt, const float* __restrict__ W, int ldw,
+                                             bool b_rows, int layout, int tid) {
+    if (prebuilt) {
+        for (int e = tid; e < 2048; e += 256) reinterpret_cast<tu32x4*>(img)[e] = reinterpret_cast<const tu32x4*>(prebuilt)[e];
+    } else {
+        build_wimage(img, W, ldw, b_rows, layout, tid, 256);
+    }
+}
+__global__ void __launch_bounds__(256) k_wimg_build(const WImgDesc* __restrict__ desc, unsigned short* __restrict__ arena) {
+    const WImgDesc d = desc[blockIdx.x];
+    build_wimage(arena + (size_t)blockIdx.x * 16384, d.W, d.ldw, d.b_rows != 0, d.layout, threadIdx.x, 256);
+}
+struct WImageCache {
+    std::vector<WImgDesc> host;
+    WImgDesc* dev = nullptr;
+    unsigned short* arena = nullptr;
+    int cap = 0, synced = 0, built = 0;
+};
+static thread_local WImageCache* g_wimg = nullptr;
+WImageCache* t_wimg_create(int capacity) {
+    WImageCache* c = new WImageCache();
+    c->cap = capacity;
+    if (hipMalloc((void**)&c->dev, sizeof(WImgDesc) * capacity) != hipSuccess || hipMalloc((void**)&c->arena, (size_t)capacity * 32768) != hipSuccess) {
+        if (c->dev) (void)hipFree(c->dev);
+        delete c;
+        return nullptr;
+    }
+    c->host.reserve(capacity);
+    return c;
+}
+void t_wimg_destroy(WImageCache* c) {
+    if (!c) return;
+    if (g_wimg == c) g_wimg = nullptr;
+    (void)hipFree(c->dev); (void)hipFree(c->arena);
+    delete c;
+}
+void t_wimg_bind(WImageCache* c) { g_wimg = c; }
+void t_wimg_clear(WImageCache* c) { if (c) { c->host.clear(); c->synced = 0; c->built = 0; } }
+void t_wimg_refresh(WImageCache* c, hipStream_t s) {
+    if (!c || c->host.empty()) return;
+    if ((int)c->host.size() > c->synced) {        // pageable source: the copy is staged before the call returns
+        (void)hipMemcpyAsync(c->dev + c->synced, c->host.data() + c->synced, sizeof(WImgDesc) * (c->host.size() - c->synced), hipMemcpyHostToDevice, s);
+        c->synced = (int)c->host.size();
+    }
+    hipLaunchKernelGGL(k_wimg_build, dim3(c->synced), dim3(256), 0, s, c->dev, c->arena);
+    c->built = c->synced;
+}
+// image of (W, ldw, orientation, layout) if the bound cache has built it; unknown blocks are registered for the next refresh
+static const unsigned short* wimg_lookup(const float* W, int ldw, bool b_rows, int layout) {
+    WImageCache* c = g_wimg;
+    if (!c) return nullptr;
+    const int n = (int)c->host.size();
+    for (int i = 0; i < n; ++i) {
+        const WImgDesc& d = c->host[i];
+        if (d.W == W && d.ldw == ldw && d.b_rows == (b_rows ? 1 : 0) && d.layout == layout) return i < c->built ? c->arena + (size_t)i * 16384 : nullptr;
+    }
+    if (n < c->cap) c->host.push_back(WImgDesc{W, ldw, b_rows ? 1 : 0, layout});
+    return nullptr;
+}
+
 // ---- NT / NN: Y[m][n] (+)= sum_k A[m][k] * B[k][n]  (+ bias[n]) (* gelu'(pre[m][n]) * mask)
 //   A = X rows (k along the row; optional GELU+dropout prologue);  B_NT: B[k][n] = W[n][k] (W row-major [N][K]);
 //   B_NN: B[k][n] = W[k][n] (W row-major [K][N]).  Wave tile 64 rows x 128 columns, workgroup = 4 waves = 256 rows.
@@ -824,19 +903,11 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
 template <bool B_ROWS>
 __global__ void __launch_bounds__(256, 1) k_mm128(TRows rows, const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
         const float* __restrict__ bias, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
-        TDrop dr, unsigned site) {
+        TDrop dr, unsigned site, const unsigned short* __restrict__ wimg) {
     __shared__ __attribute__((aligned(16))) unsigned short img[32 * 64 * 8];      // [ks][cb][lane][8] bf16
     const int R = nrows(rows);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    // B[k][col] = B_ROWS ? W[col][k] : W[k][col]; two k-adjacent elements per 32-bit LDS write
-    for (int e = tid; e < 128 * 64; e += 256) {
-        int k, col;
-        float v0, v1;
-        if (B_ROWS) { col = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)col * ldw + k; v0 = p[0]; v1 = p[1]; }
-        else { k = 2 * (e >> 7); col = e & 127; v0 = W[(size_t)k * ldw + col]; v1 = W[(size_t)(k + 1) * ldw + col]; }
-        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = col >> 5, rr = col & 31;
-        *reinterpret_cast<unsigned*>(img + (((ks * 4 + cb) * 64 + hh * 32 + rr) * 8 + j)) = tpack2(v0, v1);
-    }
+    stage_wimage(img, wimg, W, ldw, B_ROWS, 0, tid);
     __syncthreads();
     // one wave per SIMD with the whole 512-register file: 128 registers of weight fragments + a full tile of X in flight
     tu32x4 bf[8][4];
@@ -930,7 +1001,7 @@ bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* 
     if (!mm_ok(X, ldx, K, W, ldw, true)) return false;
     if (K == 128 && N == 128 && ldw % 2 == 0) {
         hipLaunchKernelGGL(k_mm128<true>, dim3(mm128_grid(rows)), dim3(256), 0, s, rows, X, ldx, W, ldw, bias, Y, ldy, beta,
-                           actA ? 1 : 0, (const float*)nullptr, dr, site);
+                           actA ? 1 : 0, (const float*)nullptr, dr, site, wimg_lookup(W, ldw, true, 0));
         return true;
     }
     // 64-row wave tiles reuse the B fragments twice; with few rows (node tensors) 32-row tiles fill more of the chip
@@ -952,7 +1023,7 @@ bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* 
     if (!mm_ok(X, ldx, K, W, ldw, false)) return false;
     if (K == 128 && N == 128 && (!epi_pre || ld_epi == 128)) {
         hipLaunchKernelGGL(k_mm128<false>, dim3(mm128_grid(rows)), dim3(256), 0, s, rows, X, ldx, W, ldw, bias, Y, ldy, beta, 0,
-                           epi_pre, dr, site);
+                           epi_pre, dr, site, wimg_lookup(W, ldw, false, 0));
         return true;
     }
     const bool small = (long long)((rows.maxrows + 255) / 256) * ((N + 127) / 128) < 2 * rn_num_cus();
@@ -1146,6 +1217,7 @@ struct EmmArgs {
     tb16* Y; int beta; int actA; const tb16* epi_pre;
     EFuse f; int has_pq, has_res;
     TDrop dr; unsigned site;
+    const unsigned short* wimg;      // prebuilt fragment image of W (WImageCache) or null
 };
 // The [E][128] x [128][128] GEMM of the per-edge Linears with the output TRANSPOSED in the accumulators: D = W' . X^T, i.e. the weight
 // is the A operand (its rows permuted so that a lane's 16 accumulator registers of a 32-channel block are two runs of 8 CONSECUTIVE
@@ -1164,16 +1236,7 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds_bias[128];
     const int R = nrows(a.rows);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const float* __restrict__ W = a.W;
-    for (int e = tid; e < 128 * 64; e += 256) {
-        int k, c;
-        float v0, v1;
-        if (B_ROWS) { c = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)c * a.ldw + k; v0 = p[0]; v1 = p[1]; }
-        else { k = 2 * (e >> 7); c = e & 127; v0 = W[(size_t)k * a.ldw + c]; v1 = W[(size_t)(k + 1) * a.ldw + c]; }
-        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = c >> 5, c5 = c & 31;
-        const int i = 8 * (c5 >> 4) + (c5 & 7), hq = (c5 >> 3) & 1, rho = (i & 3) + 8 * (i >> 2) + 4 * hq;
-        *reinterpret_cast<unsigned*>(img + (((ks * 4 + cb) * 64 + hh * 32 + rho) * 8 + j)) = tpack2(v0, v1);
-    }
+    stage_wimage(img, a.wimg, a.W, a.ldw, B_ROWS, 1, tid);
     if (tid < 128) lds_bias[tid] = a.bias ? a.bias[tid] : 0.f;
     __syncthreads();
     const tu32x4* wimg = reinterpret_cast<const tu32x4*>(img) + lane;
@@ -1340,6 +1403,7 @@ void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
     a.epi_pre = epi_pre; a.dr = dr; a.site = site;
     if (fuse) a.f = *fuse; else a.f = EFuse{nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
     a.has_pq = a.f.P != nullptr; a.has_res = a.f.res_out != nullptr;
+    a.wimg = wimg_lookup(W, ldw, w_rows, 1);
     int g = (rows.maxrows + 127) / 128;                      // 4 waves x one 32-row tile each
     const int cap = 2 * rn_num_cus();                        // two workgroups per CU (two waves per SIMD)
     const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
