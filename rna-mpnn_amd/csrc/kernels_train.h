@@ -79,15 +79,17 @@ struct EFuse {                       // optional epilogue fusions of te_gemm
 // Y[R][128] (bf16) = [beta Y] + actA(X)[R][128] . W' + bias, [* gelu'(epi_pre) * mask(site)]; W' = W^T (w_rows: W [128][ldw] as
 // nn.Linear stores it) or W (W [128][ldw] k-major).  X is bf16 (x_bf16) or f32, row stride ldx.
 void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
-             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s);
+             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s, int kvalid = 128);   // kvalid: live columns of X (the rest is zero padding)
 // dW[128][ldw] += A^T . actB(B), dbias += colsum(A)     (A, B bf16 [R][128])
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
-                unsigned site, float* dbias, hipStream_t s);
+                unsigned site, float* dbias, hipStream_t s, int cols_keep = 128);      // cols_keep: live columns of B
 void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s);
 void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);
 void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s);
+void te_edge_features(const PackInfo& pk, int k, const float* geom, const int* nbr, tb16* F, hipStream_t s);          // raw edge features, bf16 [E][128] (90 live columns)
+void te_edge_act(const PackInfo& pk, int k, const int* nbr, const tb16* pre, tb16* out, const TDrop& dr, unsigned site, hipStream_t s);   // out = valid ? drop(gelu(pre)) : 0
 void te_gelu_fwd_out(const TRows& rows, const float* x, tb16* y, int D, const TDrop& dr, unsigned site, hipStream_t s);      // y = bf16(drop(gelu(x)))
 void te_gelu_bwd_in(const TRows& rows, const tb16* dy, const float* pre, float* dx, int D, const TDrop& dr, unsigned site, hipStream_t s);   // dx = dy gelu'(pre) mask
 

@@ -118,12 +118,13 @@ void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, 
 // Every cross-workgroup sum of the backward goes through this (no float atomics): gradients are bit-reproducible.
 // Elements i >= split_at belong to a second, dense output (the bias gradient riding behind a weight-gradient tile): out2[i - split_at].
 __global__ void k_reduce_parts(const float* __restrict__ part, int nparts, size_t stride, int count, int cols,
-                               float* __restrict__ out, int ld_out, int split_at, float* __restrict__ out2) {
+                               float* __restrict__ out, int ld_out, int split_at, float* __restrict__ out2, int cols_keep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];
-    if (i < split_at) out[(size_t)(i / cols) * ld_out + (i % cols)] += s;
+#pragma unroll 8
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];       // (loads batched by the unroll, additions in order)
+    if (i < split_at) { if (i % cols < cols_keep) out[(size_t)(i / cols) * ld_out + (i % cols)] += s; }      // (columns >= cols_keep: padding of the operand)
     else out2[i - split_at] += s;
 }
 // first level of a two-level reduction: group g sums its contiguous run of partials (ascending) into tmp[g][count]
@@ -133,20 +134,22 @@ __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size
     if (i >= count) return;
     const int p0 = g * per_group, p1 = min(nparts, p0 + per_group);
     float s = 0.f;
+#pragma unroll 8
     for (int p = p0; p < p1; ++p) s += part[(size_t)p * stride + i];
     tmp[(size_t)g * count + i] = s;
 }
 // (the association order is a function of nparts alone: bit-reproducible.  tmp: 16 * count floats behind the partials)
 static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s,
-                         float* tmp = nullptr, int split_at = -1, float* out2 = nullptr) {
+                         float* tmp = nullptr, int split_at = -1, float* out2 = nullptr, int cols_keep = -1) {
     if (split_at < 0) split_at = count;
+    if (cols_keep < 0) cols_keep = cols;
     if (tmp && nparts > 96) {
         const int G = 16, per = (nparts + G - 1) / G;
         hipLaunchKernelGGL(k_reduce_groups, dim3((count + 255) / 256, G), dim3(256), 0, s, part, nparts, stride, count, per, tmp);
-        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out, split_at, out2);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out, split_at, out2, cols_keep);
         return;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out, split_at, out2);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out, split_at, out2, cols_keep);
 }
 
 // dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block; the row range is split over blockIdx.z, every split
@@ -267,6 +270,42 @@ __global__ void k_edge_features(PackInfo pk, int k, const float* __restrict__ ge
         for (int b = 0; b < 4; ++b)
             x[74 + a * 4 + b] = gi[36 + a * 3] * gj[36 + b * 3] + gi[37 + a * 3] * gj[37 + b * 3] + gi[38 + a * 3] * gj[38 + b * 3];
     for (int i = RN_ERAW; i < RN_ERAWP; ++i) x[i] = 0.f;
+}
+// bf16 variant for the mixed trainer: [E][128], columns 90..127 and absent edges zero
+__global__ void k_edge_features_b(PackInfo pk, int k, const float* __restrict__ geom, const int* __restrict__ nbr, unsigned short* __restrict__ F) {
+    const int E = pk.cu[pk.B] * k;
+    const int eid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (eid >= E) return;
+    uint4* x = reinterpret_cast<uint4*>(F + (size_t)eid * RN_D);
+    const int j = nbr[eid];
+    if (j < 0) { for (int i = 0; i < 16; ++i) x[i] = make_uint4(0u, 0u, 0u, 0u); return; }
+    const float* gi = geom + (size_t)(eid / k) * RN_GEOM;
+    const float* gj = geom + (size_t)j * RN_GEOM;
+    float v[96];
+    for (int a = 0; a < 7; ++a)
+        for (int b = 0; b < 7; ++b) {
+            float dx = gi[a * 3] - gj[b * 3], dy = gi[a * 3 + 1] - gj[b * 3 + 1], dz = gi[a * 3 + 2] - gj[b * 3 + 2];
+            v[a * 7 + b] = sqrtf(dx * dx + dy * dy + dz * dz + kSEPS);
+        }
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            v[49 + a * 5 + b] = gi[21 + a * 3] * gj[21 + b * 3] + gi[22 + a * 3] * gj[22 + b * 3] + gi[23 + a * 3] * gj[23 + b * 3];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+            v[74 + a * 4 + b] = gi[36 + a * 3] * gj[36 + b * 3] + gi[37 + a * 3] * gj[37 + b * 3] + gi[38 + a * 3] * gj[38 + b * 3];
+    for (int i = RN_ERAW; i < 96; ++i) v[i] = 0.f;
+    auto pk2 = [](float a, float b) {                     // round-to-nearest-even bf16 pair (tpack2 is defined further down)
+        typedef __attribute__((ext_vector_type(2))) float f2; typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+        f2 t = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(t, b2));
+    };
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = make_uint4(pk2(v[8 * i], v[8 * i + 1]), pk2(v[8 * i + 2], v[8 * i + 3]), pk2(v[8 * i + 4], v[8 * i + 5]), pk2(v[8 * i + 6], v[8 * i + 7]));
+    for (int i = 12; i < 16; ++i) x[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+void te_edge_features(const PackInfo& pk, int k, const float* geom, const int* nbr, tb16* F, hipStream_t s) {
+    size_t total = (size_t)pk.Nmax * k;
+    hipLaunchKernelGGL(k_edge_features_b, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, pk, k, geom, nbr, F);
 }
 void t_edge_features(const PackInfo& pk, int k, const float* geom, const int* nbr, float* F, hipStream_t s) {
     size_t total = (size_t)pk.Nmax * k;
@@ -771,13 +810,13 @@ __device__ __forceinline__ tu32x4 frag_col(const float* __restrict__ src, int ld
 // the row permutation that makes a lane's accumulators two runs of 8 consecutive channels.  A kernel builds its image itself
 // (32 rounds of scattered 4-byte loads per thread, ~10 us of serial latency before the first tile) unless the caller's WImageCache has it:
 // the cache rebuilds ALL registered images in one launch at the start of a training forward.
-struct WImgDesc { const float* W; int ldw; int b_rows; int layout; };
-__device__ __forceinline__ void build_wimage(unsigned short* img, const float* __restrict__ W, int ldw, bool b_rows, int layout, int tid, int nthreads) {
+struct WImgDesc { const float* W; int ldw; int b_rows; int layout; int kvalid; };     // k >= kvalid: zeros (the 90-wide raw edge features)
+__device__ __forceinline__ void build_wimage(unsigned short* img, const float* __restrict__ W, int ldw, bool b_rows, int layout, int kvalid, int tid, int nthreads) {
     for (int e = tid; e < 128 * 64; e += nthreads) {
         int k, c;
         float v0, v1;
-        if (b_rows) { c = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)c * ldw + k; v0 = p[0]; v1 = p[1]; }
-        else { k = 2 * (e >> 7); c = e & 127; v0 = W[(size_t)k * ldw + c]; v1 = W[(size_t)(k + 1) * ldw + c]; }
+        if (b_rows) { c = e >> 6; k = 2 * (e & 63); const float* p = W + (size_t)c * ldw + k; v0 = k < kvalid ? p[0] : 0.f; v1 = k + 1 < kvalid ? p[1] : 0.f; }
+        else { k = 2 * (e >> 7); c = e & 127; v0 = k < kvalid ? W[(size_t)k * ldw + c] : 0.f; v1 = k + 1 < kvalid ? W[(size_t)(k + 1) * ldw + c] : 0.f; }
         const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7, cb = c >> 5, c5 = c & 31;
         int rr = c5;
         if (layout == 1) { const int i = 8 * (c5 >> 4) + (c5 & 7), hq = (c5 >> 3) & 1; rr = (i & 3) + 8 * (i >> 2) + 4 * hq; }
@@ -785,16 +824,16 @@ __device__ __forceinline__ void build_wimage(unsigned short* img, const float* _
     }
 }
 __device__ __forceinline__ void stage_wimage(unsigned short* img, const unsigned short* __restrict__ prebuilt, const float* __restrict__ W, int ldw,
-                                             bool b_rows, int layout, int tid) {
+                                             bool b_rows, int layout, int tid, int kvalid = 128) {
     if (prebuilt) {
         for (int e = tid; e < 2048; e += 256) reinterpret_cast<tu32x4*>(img)[e] = reinterpret_cast<const tu32x4*>(prebuilt)[e];
     } else {
-        build_wimage(img, W, ldw, b_rows, layout, tid, 256);
+        build_wimage(img, W, ldw, b_rows, layout, kvalid, tid, 256);
     }
 }
 __global__ void __launch_bounds__(256) k_wimg_build(const WImgDesc* __restrict__ desc, unsigned short* __restrict__ arena) {
     const WImgDesc d = desc[blockIdx.x];
-    build_wimage(arena + (size_t)blockIdx.x * 16384, d.W, d.ldw, d.b_rows != 0, d.layout, threadIdx.x, 256);
+    build_wimage(arena + (size_t)blockIdx.x * 16384, d.W, d.ldw, d.b_rows != 0, d.layout, d.kvalid, threadIdx.x, 256);
 }
 struct WImageCache {
     std::vector<WImgDesc> host;
@@ -832,15 +871,15 @@ void t_wimg_refresh(WImageCache* c, hipStream_t s) {
     c->built = c->synced;
 }
 // image of (W, ldw, orientation, layout) if the bound cache has built it; unknown blocks are registered for the next refresh
-static const unsigned short* wimg_lookup(const float* W, int ldw, bool b_rows, int layout) {
+static const unsigned short* wimg_lookup(const float* W, int ldw, bool b_rows, int layout, int kvalid = 128) {
     WImageCache* c = g_wimg;
     if (!c) return nullptr;
     const int n = (int)c->host.size();
     for (int i = 0; i < n; ++i) {
         const WImgDesc& d = c->host[i];
-        if (d.W == W && d.ldw == ldw && d.b_rows == (b_rows ? 1 : 0) && d.layout == layout) return i < c->built ? c->arena + (size_t)i * 16384 : nullptr;
+        if (d.W == W && d.ldw == ldw && d.b_rows == (b_rows ? 1 : 0) && d.layout == layout && d.kvalid == kvalid) return i < c->built ? c->arena + (size_t)i * 16384 : nullptr;
     }
-    if (n < c->cap) c->host.push_back(WImgDesc{W, ldw, b_rows ? 1 : 0, layout});
+    if (n < c->cap) c->host.push_back(WImgDesc{W, ldw, b_rows ? 1 : 0, layout, kvalid});
     return nullptr;
 }
 
@@ -1218,6 +1257,7 @@ struct EmmArgs {
     EFuse f; int has_pq, has_res;
     TDrop dr; unsigned site;
     const unsigned short* wimg;      // prebuilt fragment image of W (WImageCache) or null
+    int kvalid;                      // columns of X / rows of W' beyond it do not exist (treated as zero weights)
 };
 // The [E][128] x [128][128] GEMM of the per-edge Linears with the output TRANSPOSED in the accumulators: D = W' . X^T, i.e. the weight
 // is the A operand (its rows permuted so that a lane's 16 accumulator registers of a 32-channel block are two runs of 8 CONSECUTIVE
@@ -1236,7 +1276,7 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds_bias[128];
     const int R = nrows(a.rows);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    stage_wimage(img, a.wimg, a.W, a.ldw, B_ROWS, 1, tid);
+    stage_wimage(img, a.wimg, a.W, a.ldw, B_ROWS, 1, tid, a.kvalid);
     if (tid < 128) lds_bias[tid] = a.bias ? a.bias[tid] : 0.f;
     __syncthreads();
     const tu32x4* wimg = reinterpret_cast<const tu32x4*>(img) + lane;
@@ -1397,19 +1437,21 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
     }
 }
 void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
-             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s) {
+             int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s, int kvalid) {
     EmmArgs a;
     a.rows = rows; a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.Y = Y; a.beta = beta; a.actA = actA ? 1 : 0;
     a.epi_pre = epi_pre; a.dr = dr; a.site = site;
     if (fuse) a.f = *fuse; else a.f = EFuse{nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
     a.has_pq = a.f.P != nullptr; a.has_res = a.f.res_out != nullptr;
-    a.wimg = wimg_lookup(W, ldw, w_rows, 1);
+    a.kvalid = kvalid;
+    a.wimg = wimg_lookup(W, ldw, w_rows, 1, kvalid);
     int g = (rows.maxrows + 127) / 128;                      // 4 waves x one 32-row tile each
     const int cap = 2 * rn_num_cus();                        // two workgroups per CU (two waves per SIMD)
     const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
     const int ep = a.has_pq ? 1 : (epi_pre ? 2 : (beta ? 3 : 0));
 #define EMM_GO(BR, TXT, EPV, ACTV, RESV) hipLaunchKernelGGL((k_emm128<BR, TXT, EPV, ACTV, RESV>), grid, dim3(256), 0, s, a)
     if (!x_bf16 && w_rows && ep == 0 && !actA && !a.has_res) EMM_GO(true, float, 0, false, false);                 // node rows -> bf16 P / Q tables
+    else if (x_bf16 && w_rows && ep == 0 && !actA && !a.has_res) EMM_GO(true, tb16, 0, false, false);             // edge embedding: raw features -> pe1
     else if (x_bf16 && w_rows && ep == 1 && !actA && !a.has_res) EMM_GO(true, tb16, 1, false, false);             // first Linear + P + Q
     else if (x_bf16 && w_rows && ep == 1 && !actA && a.has_res) EMM_GO(true, tb16, 1, false, true);               // ... of a depth-1 edge update
     else if (x_bf16 && w_rows && ep == 0 && actA && !a.has_res) EMM_GO(true, tb16, 0, true, false);               // second Linear (message)
@@ -1531,7 +1573,7 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
         }
 }
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
-                unsigned site, float* dbias, hipStream_t s) {
+                unsigned site, float* dbias, hipStream_t s, int cols_keep) {
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)520 * 128) / mk) - 16;
     int splits = (rows.maxrows + 1023) / 1024;
@@ -1545,7 +1587,7 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
     float* tmp = sc.p + (size_t)splits * pstride;
     hipLaunchKernelGGL(k_emm_tn, dim3(1, 1, splits), dim3(256), 0, s, rows, A, B, sc.p, pstride, rps, actB ? 1 : 0, dr, site,
                        dbias ? sc.p + mk : (float*)nullptr);
-    reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw, s, tmp, (int)mk, dbias);
+    reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw, s, tmp, (int)mk, dbias, cols_keep);
 }
 
 // ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
@@ -1607,6 +1649,19 @@ __global__ void k_eelem(PackInfo pk, int k, const int* __restrict__ nbr, int mod
         const bool valid = nbr[id >> 4] >= 0;
         tu32x4* xp = reinterpret_cast<tu32x4*>(x) + id;
         if (mode == 1) { if (!valid) *xp = tu32x4{0u, 0u, 0u, 0u}; continue; }
+        if (mode == 2) {                                      // x = valid ? drop(gelu(pre2)) : 0
+            tu32x4 o2 = {0u, 0u, 0u, 0u};
+            if (valid) {
+                float pr[8], dm[8];
+                unpack8(reinterpret_cast<const tu32x4*>(pre2)[id], pr);
+                drop8(dr, drop_key(dr, site), (unsigned)id, dm);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pr[q] = gelu_fast(pr[q]) * dm[q];
+                o2 = tpack8(pr);
+            }
+            *xp = o2;
+            continue;
+        }
         tu32x4 o = {0u, 0u, 0u, 0u};
         if (valid) {
             float d[8], pr[8];
@@ -1624,6 +1679,9 @@ __global__ void k_eelem(PackInfo pk, int k, const int* __restrict__ nbr, int mod
 static unsigned eelem_grid(const PackInfo& pk, int k) { size_t g = ((size_t)pk.Nmax * k * 16 + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
 void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s) {
     hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 0, de, pre2, dpre2, dr, site);
+}
+void te_edge_act(const PackInfo& pk, int k, const int* nbr, const tb16* pre, tb16* out, const TDrop& dr, unsigned site, hipStream_t s) {
+    hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 2, nullptr, pre, out, dr, site);
 }
 void te_zero_invalid(const PackInfo& pk, int k, const int* nbr, tb16* x, hipStream_t s) {
     hipLaunchKernelGGL(k_eelem, dim3(eelem_grid(pk, k)), dim3(256), 0, s, pk, k, nbr, 1, nullptr, nullptr, x, TDrop{0, 0, 1.f}, 0u);
