@@ -48,6 +48,11 @@ __device__ __forceinline__ V3 unit_nan0(V3 a) { const float n = sqrtf(dot(a, a))
 // F.normalize: v / max(|v|, 1e-12)
 __device__ __forceinline__ V3 unit_eps(V3 a) { return scale(a, 1.0f / fmaxf(sqrtf(dot(a, a)), 1e-12f)); }
 __device__ __forceinline__ float gelu_e(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ tb16 rd_bf(float v) {          // round-to-nearest-even bf16
+    typedef __attribute__((ext_vector_type(2))) float f2; typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    f2 t = {v, 0.f};
+    return (tb16)(__builtin_bit_cast(unsigned, __builtin_convertvector(t, b2)) & 0xffffu);
+}
 
 // atom q of the FLATTENED 6-atom chain of batch row b (feature.py:85-86,138): coordinates of a valid residue, zeros for a padded
 // one (the collate zero-fills, utils/data.py:113-115); `inside` = the position exists in the (B, T) tensor at all
@@ -227,7 +232,8 @@ __global__ void k_rd_edge(PackInfo pk, int K, const int* __restrict__ nbr, const
 // mode 0: functional.Normalize (functional.py:83-101): unbiased variance, gain (x - mu) / (sqrt(var + eps) + eps) + bias, eps 1e-6
 // mode 1: nn.LayerNorm(x + r): biased variance, eps 1e-5
 __global__ void __launch_bounds__(256) k_rd_rownorm(const int* __restrict__ ntot_p, int mul, const float* __restrict__ x, const float* __restrict__ res,
-                                                    const float* __restrict__ gain, const float* __restrict__ bias, int mode, float* __restrict__ y) {
+                                                    const float* __restrict__ gain, const float* __restrict__ bias, int mode, float* __restrict__ y,
+                                                    tb16* __restrict__ yb) {
     const size_t R = (size_t)*ntot_p * mul;
     const int lane = threadIdx.x & 63;
     for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += (size_t)gridDim.x * 4) {
@@ -244,16 +250,17 @@ __global__ void __launch_bounds__(256) k_rd_rownorm(const int* __restrict__ ntot
         float inv;
         if (mode == 0) inv = 1.0f / (sqrtf(q / 127.f + 1e-6f) + 1e-6f);
         else inv = 1.0f / sqrtf(q / 128.f + 1e-5f);
-        y[row * RD_H + lane] = gain[lane] * d0 * inv + bias[lane];
-        y[row * RD_H + 64 + lane] = gain[64 + lane] * d1 * inv + bias[64 + lane];
+        const float o0 = gain[lane] * d0 * inv + bias[lane], o1 = gain[64 + lane] * d1 * inv + bias[64 + lane];
+        if (yb) { yb[row * RD_H + lane] = rd_bf(o0); yb[row * RD_H + 64 + lane] = rd_bf(o1); }      // bf16 edge tensors of the bf16 path
+        else { y[row * RD_H + lane] = o0; y[row * RD_H + 64 + lane] = o1; }
     }
 }
 static void rd_rownorm(const int* ntot, int mul, size_t maxrows, const float* x, const float* res, const float* gain, const float* bias, int mode,
-                       float* y, hipStream_t s) {
+                       float* y, hipStream_t s, tb16* yb = nullptr) {
     size_t g = (maxrows + 3) / 4;
     if (g > 8192) g = 8192;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_rd_rownorm, dim3((unsigned)g), dim3(256), 0, s, ntot, mul, x, res, gain, bias, mode, y);
+    hipLaunchKernelGGL(k_rd_rownorm, dim3((unsigned)g), dim3(256), 0, s, ntot, mul, x, res, gain, bias, mode, y, yb);
 }
 
 // dh[p][c] = sum over the valid slots of GELU(pre[(p, s)][c]) / scale      (mpnn.py:32-33: scatter_sum / 30, a segmented sum here)
@@ -266,6 +273,23 @@ __global__ void __launch_bounds__(128) k_rd_segsum(PackInfo pk, int K, const int
     for (int sl = 0; sl < K; ++sl)
         if (nbr[(size_t)p * K + sl] >= 0) s += gelu_e(pre[((size_t)p * K + sl) * RD_H + c]);
     out[(size_t)p * RD_H + c] = s * inv_scale;
+}
+
+// the same on a bf16 pre-activation tensor (bf16 path): one thread = two adjacent channels
+__global__ void __launch_bounds__(256) k_rd_segsum_b(PackInfo pk, int K, const int* __restrict__ nbr, const tb16* __restrict__ pre, float inv_scale,
+                                                     float* __restrict__ out) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= pk.cu[pk.B]) return;
+    const int c = 2 * (threadIdx.x & 63);
+    float s0 = 0.f, s1 = 0.f;
+    for (int sl = 0; sl < K; ++sl) {
+        const size_t er = (size_t)p * K + sl;
+        if (nbr[er] >= 0) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(pre + er * RD_H + c);
+            s0 += gelu_e(__uint_as_float(w << 16)); s1 += gelu_e(__uint_as_float(w & 0xffff0000u));
+        }
+    }
+    out[(size_t)p * RD_H + c] = s0 * inv_scale; out[(size_t)p * RD_H + c + 1] = s1 * inv_scale;
 }
 
 // ------------------------------------------------------------------------------------------ handle
@@ -440,6 +464,7 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
     ZeroRegions z{};
     z.ptr[0] = w.hV + Nmax * RD_H; z.words[0] = RD_H; z.ptr[1] = w.hV2 + Nmax * RD_H; z.words[1] = RD_H;
     z.ptr[2] = w.pq + Nmax * 256; z.words[2] = 256; z.n = 3;
+    if (r.mixed) { z.ptr[3] = reinterpret_cast<tb16*>(w.pq) + (2 * Nmax + 1) * RD_H; z.words[3] = RD_H / 2; z.n = 4; }     // row Nmax of the bf16 Q table
     launch_zero_regions(z, s);
     // ---- RNAFeatures.forward (feature.py:157-248)
     hipLaunchKernelGGL(k_rd_residue, dim3((unsigned)((Nmax + 63) / 64)), dim3(64), 0, s, X, r.pk, w.coords_p, w.frame, w.node_raw);
@@ -456,10 +481,26 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
     t_gemm(r.rn(), w.node_raw, RD_NODEP, RD_NODEP, c->der + c->node_emb.wt, RD_H, rdp(c, c->node_emb.b), RD_H, w.hV2, RD_H, 0, s);
     rd_rownorm(r.pk.cu + B, 1, Nmax, w.hV2, nullptr, rdp(c, c->nn_g), rdp(c, c->nn_b), 0, w.hV, s);
     t_gemm(r.re(), w.edge_raw, RD_EDGEP, RD_EDGEP, c->der + c->edge_emb.wt, RD_H, rdp(c, c->edge_emb.b), RD_H, w.E1, RD_H, 0, s);
-    rd_rownorm(r.pk.cu + B, K, Nmax * K, w.E1, nullptr, rdp(c, c->ne_g), rdp(c, c->ne_b), 0, w.hE, s);
+    rd_rownorm(r.pk.cu + B, K, Nmax * K, w.E1, nullptr, rdp(c, c->ne_g), rdp(c, c->ne_b), 0, w.hE, s, r.mixed ? reinterpret_cast<tb16*>(w.hE) : nullptr);
     // ---- L x MPNNLayer (rdesign.py:84-86, mpnn.py:31-37)
     for (auto& L : c->layers) {
         // message Linear 0 on cat[h_E, h_V[centre], h_V[neighbour]] = W_e.h_E + P[centre] + Q[neighbour]
+        if (r.mixed) {     // bf16 edge tensors, the edge GEMM of the bf16-mixed trainer (kernels_train.h: te_gemm): P + Q in the epilogue, GELU in the operand load
+            tb16* Pt = reinterpret_cast<tb16*>(w.pq);
+            tb16* Qt = Pt + (Nmax + 1) * RD_H;
+            const float* w0 = rdp(c, L.msg[0].w);                                                            // [128][384] = [W_e | W_centre | W_neighbour]
+            te_gemm(r.rn(), w.hV, false, RD_H, w0 + RD_H, 3 * RD_H, true, rdp(c, L.msg[0].b), Pt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
+            te_gemm(r.rn(), w.hV, false, RD_H, w0 + 2 * RD_H, 3 * RD_H, true, nullptr, Qt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
+            EFuse f{Pt, Qt, w.nbr, K, (int)Nmax, nullptr, nullptr, 0u};
+            tb16* cur = reinterpret_cast<tb16*>(w.E1);
+            tb16* nxt = reinterpret_cast<tb16*>(w.E2);
+            te_gemm(r.re(), w.hE, true, RD_H, w0, 3 * RD_H, true, nullptr, cur, 0, false, nullptr, &f, r.nodrop, 0u, s);
+            for (size_t i = 1; i < L.msg.size(); ++i) {
+                te_gemm(r.re(), cur, true, RD_H, rdp(c, L.msg[i].w), RD_H, true, rdp(c, L.msg[i].b), nxt, 0, true, nullptr, nullptr, r.nodrop, 0u, s);
+                tb16* t = cur; cur = nxt; nxt = t;
+            }
+            hipLaunchKernelGGL(k_rd_segsum_b, dim3((unsigned)((Nmax + 3) / 4)), dim3(256), 0, s, r.pk, K, w.nbr, cur, 1.0f / 30.0f, w.dh);
+        } else {
         rd_mm(r, r.rn(), w.hV, RD_H, L.msg[0], RD_H, RD_H, true, w.pq, 256, 0, false, nullptr);            // P = h_V W_c^T + b
         rd_mm(r, r.rn(), w.hV, RD_H, L.msg[0], 2 * RD_H, RD_H, false, w.pq + RD_H, 256, 0, false, nullptr); // Q = h_V W_n^T
         rd_mm(r, r.re(), w.hE, RD_H, L.msg[0], 0, RD_H, false, w.E1, RD_H, 0, false, nullptr);
@@ -471,6 +512,7 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
             float* t = cur; cur = nxt; nxt = t;
         }
         hipLaunchKernelGGL(k_rd_segsum, dim3((unsigned)Nmax), dim3(128), 0, s, r.pk, K, w.nbr, cur, 1.0f / 30.0f, w.dh);
+        }
         rd_rownorm(r.pk.cu + B, 1, Nmax, w.hV, w.dh, rdp(c, L.n1w), rdp(c, L.n1b), 1, w.hV2, s);            // norm1(h_V + dh)
         // dense FFN
         const float* x = w.hV2;
