@@ -902,15 +902,63 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // raw operand loads one k-step ahead of the MFMAs that use them (a fragment straight from global memory is a load -> wait -> use chain
+    // per k-step otherwise): rows / columns clamped, out-of-range elements zeroed when the fragment is finished
+    float ra[MT][8], rb[4][8];
+    auto load_step = [&](int k0) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int row = m0 + 32 * a + r;
+            const float* p = X + (size_t)(row < R ? row : 0) * ldx + k0 + 8 * h;
+            const tf32x4 u = *reinterpret_cast<const tf32x4*>(p), v = *reinterpret_cast<const tf32x4*>(p + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ra[a][q] = u[q]; ra[a][4 + q] = v[q]; }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = n0 + 32 * b + r;
+            const int cc = col < N ? col : 0;
+            if (B_ROWS) {
+                const float* p = W + (size_t)cc * ldw + k0 + 8 * h;
+                const tf32x4 u = *reinterpret_cast<const tf32x4*>(p), v = *reinterpret_cast<const tf32x4*>(p + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { rb[b][q] = u[q]; rb[b][4 + q] = v[q]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int kk = k0 + 8 * h + j; rb[b][j] = W[(size_t)(kk < K ? kk : 0) * ldw + cc]; }
+            }
+        }
+    };
+    load_step(0);
     for (int k0 = 0; k0 < K; k0 += 16) {
         tu32x4 af[MT], bf[4];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) af[a] = frag_row(X, ldx, m0 + 32 * a + r, R, k0 + 8 * h, actA != 0, dr, site, K);
+        for (int a = 0; a < MT; ++a) {
+            const int row = m0 + 32 * a + r;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ra[a][q];
+            if (actA) {
+                float dm[8];
+                drop8(dr, drop_key(dr, site), (unsigned)(((unsigned long long)row * K + k0 + 8 * h) >> 3), dm);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * dm[q];
+            }
+            if (row >= R) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
+            af[a] = tpack8(v);
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (B_ROWS) bf[b] = frag_row(W, ldw, n0 + 32 * b + r, N, k0 + 8 * h, false, dr, 0u, 0);
-            else bf[b] = frag_col(W, ldw, k0 + 8 * h, K, n0 + 32 * b + r, N, false, dr, 0u, 0);
+            const int col = n0 + 32 * b + r;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (col < N && (B_ROWS || k0 + 8 * h + q < K)) ? rb[b][q] : 0.f;
+            bf[b] = tpack8(v);
         }
+        if (k0 + 16 < K) load_step(k0 + 16);
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -920,18 +968,27 @@ __global__ void __launch_bounds__(256) k_mm(TRows rows, const float* __restrict_
     for (int b = 0; b < 4; ++b) {
         const int col = n0 + 32 * b + r;
         const bool colok = col < N;
+        const int cc = colok ? col : 0;
         const float bv = (bias && colok) ? bias[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
+            // the loads of a tile (old Y for beta, the taped pre-activation) go out as one batch with clamped rows
+            float yo[16], pr[16];
+            if (beta) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) yo[i] = Y[(size_t)min(m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h, R - 1) * ldy + cc];
+            }
+            if (epi_pre) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pr[i] = epi_pre[(size_t)min(m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h, R - 1) * ld_epi + cc];
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = m0 + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (colok && row < R) {
-                    float v = acc[a][b][i] + bv;
-                    if (epi_pre) v *= gelu_d_fast(epi_pre[(size_t)row * ld_epi + col]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
-                    float* y = Y + (size_t)row * ldy + col;
-                    *y = beta ? *y + v : v;
-                }
+                float v = acc[a][b][i] + bv;
+                if (epi_pre) v *= gelu_d_fast(pr[i]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
+                if (beta) v += yo[i];
+                if (colok && row < R) Y[(size_t)row * ldy + col] = v;
             }
         }
     }
