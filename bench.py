@@ -331,7 +331,7 @@ def train_leg(args, model, dev_batches, n_steps, world, dev, red_dev, barrier, d
     t_max, nt_total = shard.reduce_job(el, nt, red_dev)
     return {"value": nt_total * n_steps / t_max, "unit": "nucleotides/s (training step: fwd + bwd + all-reduce + Adam)",
             "steps": n_steps, "ms_per_step": t_max / n_steps * 1e3, "rnas_per_rank_per_step": nb,
-            "dtype": "bf16-mixed (MFMA GEMMs, f32 accumulate / elementwise)" if args.precision == "bf16" else "f32",
+            "dtype": "bf16-mixed (MFMA GEMMs, f32 accumulate; per-edge tape and gradients stored as bf16)" if args.precision == "bf16" else "f32",
             "allreduce_ms_per_step": ar_ms / n_steps if world > 1 else None, "allreduce_bytes": 3536900 * 4}
 
 
