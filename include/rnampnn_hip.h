@@ -218,6 +218,22 @@ int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches,
 const char* rnampnn_last_error(void);
 const char* rnampnn_version(void);
 
+/* ---- Gradient-boosted-tree read-out (PARITY UNPINNED: xgboost is not installed, no fitted model ships).
+ * Replaces `self.xgb_readout.predict(embedding)` (rnampnn/model/rnampnn.py:136-145,297-298) for a fitted `multi:softmax` gbtree model
+ * given as the arrays of XGBoost's JSON model format (`learner.gradient_booster.model.trees[*].{left_children,right_children,
+ * split_indices,split_conditions,default_left}` concatenated over the trees, `tree_info` = class of each tree).  Host arrays, copied.
+ * Rule: at an internal node go left iff x[split_index] < split_condition (NaN: default_left); a leaf adds split_conditions[leaf] to the
+ * margin of its tree's class; prediction = first argmax of the margins.  X (n_rows, ldx >= num_feature) f32 device, outputs device. */
+typedef struct rnampnn_gbdt* rnampnn_gbdt_handle;
+int rnampnn_gbdt_create(int32_t num_trees, int32_t num_class, int32_t num_feature, float base_score, const int32_t* tree_offsets,
+                        const int32_t* tree_class, const int32_t* left_children, const int32_t* right_children,
+                        const int32_t* split_indices, const float* split_conditions, const uint8_t* default_left,
+                        rnampnn_gbdt_handle* out);
+int rnampnn_gbdt_destroy(rnampnn_gbdt_handle g);
+int rnampnn_gbdt_predict(rnampnn_gbdt_handle g, const float* X, int32_t n_rows, int32_t ldx, float* margin /* (n_rows,num_class) or null */,
+                         int32_t* argmax_out /* (n_rows) or null */, void* stream);
+const char* rnampnn_gbdt_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

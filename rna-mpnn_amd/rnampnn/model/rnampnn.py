@@ -207,10 +207,23 @@ class RNAMPNN(NativeModule):
         logits = self.forward(coords, mask, T_norm=T_norm)
         return sample_from_logits(logits, mask, temperature, n_samples, seed)
 
+    def load_xgb_readout(self, model) -> None:
+        """Attach a fitted multi:softmax XGBoost model (JSON model file / dict, ``Booster.save_model``) as ``self.xgb_readout``: the
+        device-side tree read-out of ``rnampnn/model/xgb.py`` (parity unpinned).  The reference unpickles its
+        ``XGB-V*.pkl`` in ``on_load_checkpoint`` (rnampnn.py:232-266); pickles are never loaded here."""
+        from .xgb import GBDTReadout
+        self.xgb_readout = GBDTReadout.from_xgboost_json(model)
+
     @torch.no_grad()
     def predict_sequences(self, coords: torch.Tensor, mask: torch.Tensor) -> List[str]:
-        """Readout-argmax decode to strings (what ``predict`` writes, rnampnn.py:300-305, with the
-        Readout standing in for the missing XGBoost classifier)."""
+        """What ``predict`` writes (rnampnn.py:280-305): with a tree model loaded (``load_xgb_readout``) the reference's route -
+        ``embedding`` (B*T, 256) -> ``xgb_readout.predict`` -> valid positions; otherwise the Readout argmax stands in for the
+        unfitted classifier."""
+        if getattr(self, "xgb_readout", None) is not None:
+            emb = self.embedding(coords, mask)
+            pred = self.xgb_readout.predict(emb).cpu()
+            valid = mask.cpu() == 1
+            return ["".join(REVERSE_VOCAB[int(i)] for i in row[v]) for row, v in zip(pred, valid)]
         logits = self.forward(coords, mask)
         pred, _, _ = argmax_recovery(logits, mask, None)
         pred = pred.cpu()
