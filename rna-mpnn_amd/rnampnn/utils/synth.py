@@ -136,3 +136,31 @@ def synth_batch(lengths: Iterable[int], first_index: int = 0, seed: int = 0,
         mask[b, :n] = 1.0
         labels[b, :n] = synth_labels(n, first_index + b, seed)
     return coords, mask, labels
+
+
+def synth_xgb_json(n_rounds, num_class, num_feature, max_depth, seed):
+    """A seeded random forest in XGBoost's JSON model schema (``Booster.save_model``): n_rounds x num_class trees, depth-first node
+    numbering (children after parents) - synthetic stand-in for the fitted read-out the reference does not ship (row F4)."""
+    rng = np.random.RandomState(seed)
+    trees, info = [], []
+    for r in range(n_rounds):
+        for c in range(num_class):
+            L, R, F, T, D = [], [], [], [], []
+
+            def grow(depth):
+                i = len(L)
+                L.append(-1); R.append(-1); F.append(0); T.append(0.0); D.append(0)
+                if depth < max_depth and (depth < 2 or rng.rand() < 0.75):
+                    F[i] = int(rng.randint(num_feature)); T[i] = float(np.float32(rng.randn())); D[i] = int(rng.rand() < 0.5)
+                    L[i] = grow(depth + 1)
+                    R[i] = grow(depth + 1)
+                else:
+                    T[i] = float(np.float32(0.3 * rng.randn()))          # leaf value
+                return i
+            grow(0)
+            trees.append(dict(left_children=L, right_children=R, split_indices=F, split_conditions=T, default_left=D,
+                              categories_nodes=[], id=len(trees)))
+            info.append(c)
+    return {"learner": {"learner_model_param": {"num_class": str(num_class), "num_feature": str(num_feature), "base_score": "5E-1"},
+                        "gradient_booster": {"name": "gbtree", "model": {"tree_info": info, "trees": trees}},
+                        "objective": {"name": "multi:softmax"}}, "version": [2, 1, 1]}

@@ -9,31 +9,7 @@ import torch
 from oracle import gbdt_oracle
 
 
-def random_xgb_json(n_rounds, num_class, num_feature, max_depth, seed):
-    """A syntactically faithful XGBoost JSON model: n_rounds x num_class trees, depth-first node numbering (children after parents)."""
-    rng = np.random.RandomState(seed)
-    trees, info = [], []
-    for r in range(n_rounds):
-        for c in range(num_class):
-            L, R, F, T, D = [], [], [], [], []
-
-            def grow(depth):
-                i = len(L)
-                L.append(-1); R.append(-1); F.append(0); T.append(0.0); D.append(0)
-                if depth < max_depth and (depth < 2 or rng.rand() < 0.75):
-                    F[i] = int(rng.randint(num_feature)); T[i] = float(np.float32(rng.randn())); D[i] = int(rng.rand() < 0.5)
-                    L[i] = grow(depth + 1)
-                    R[i] = grow(depth + 1)
-                else:
-                    T[i] = float(np.float32(0.3 * rng.randn()))          # leaf value
-                return i
-            grow(0)
-            trees.append(dict(left_children=L, right_children=R, split_indices=F, split_conditions=T, default_left=D,
-                              categories_nodes=[], id=len(trees)))
-            info.append(c)
-    return {"learner": {"learner_model_param": {"num_class": str(num_class), "num_feature": str(num_feature), "base_score": "5E-1"},
-                        "gradient_booster": {"name": "gbtree", "model": {"tree_info": info, "trees": trees}},
-                        "objective": {"name": "multi:softmax"}}, "version": [2, 1, 1]}
+from rnampnn.utils.synth import synth_xgb_json as random_xgb_json  # noqa: E402
 
 
 def test_json_parser_and_oracle_on_a_hand_made_tree(tmp_path):

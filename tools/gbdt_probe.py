@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Throughput of the device-side tree read-out (row F4) at the reference's model shape: 150 rounds x 4 classes, depth 8, 256 features,
-on the embeddings of a C2 batch (30,559 rows).  Seeded random forest in XGBoost's JSON schema (tests/test_gbdt.py)."""
+on the embeddings of a C2 batch (30,559 rows).  Seeded random forest in XGBoost's JSON schema (rnampnn/utils/synth.py: synth_xgb_json)."""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rna-mpnn_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rna-mpnn_amd")); 
 import __graft_entry__ as g
 g.load_only()
 from rnampnn.model.xgb import GBDTReadout, parse_xgboost_json
-from test_gbdt import random_xgb_json
+from rnampnn.utils.synth import synth_xgb_json as random_xgb_json
 a = parse_xgboost_json(random_xgb_json(150, 4, 256, 8, seed=1))
 gb = GBDTReadout(a)
 x = torch.randn(30559, 256, device="cuda")
