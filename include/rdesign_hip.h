@@ -78,7 +78,8 @@ int rdesign_forward(rdesign_handle h, const float* X, const float* mask, int32_t
                     int64_t* edge_index, float* node_raw, float* edge_raw, void* ws, size_t ws_bytes, void* stream);
 
 /* Readout.forward (functional.py:123-126) on n_rows caller rows of 128 floats -> logits (n_rows,4).
- * Workspace: rdesign_workspace_bytes(h, 1, n_rows). */
+ * Workspace: rdesign_readout_workspace_bytes(h, n_rows) (node-sized buffers only). */
+size_t rdesign_readout_workspace_bytes(rdesign_handle h, int32_t n_rows);
 int rdesign_readout(rdesign_handle h, const float* h_V, int32_t n_rows, float* logits, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -77,8 +77,9 @@ struct EFuse {                       // optional epilogue fusions of te_gemm
     unsigned site2;
 };
 // Y[R][128] (bf16) = [beta Y] + actA(X)[R][128] . W' + bias, [* gelu'(epi_pre) * mask(site)]; W' = W^T (w_rows: W [128][ldw] as
-// nn.Linear stores it) or W (W [128][ldw] k-major).  X is bf16 (x_bf16) or f32, row stride ldx.
-void te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
+// nn.Linear stores it) or W (W [128][ldw] k-major).  X is bf16 (x_bf16) or f32, row stride ldx.  Returns false (nothing launched) for a
+// combination of options that is not instantiated.
+bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float* W, int ldw, bool w_rows, const float* bias, tb16* Y,
              int beta, bool actA, const tb16* epi_pre, const EFuse* fuse, const TDrop& dr, unsigned site, hipStream_t s, int kvalid = 128);   // kvalid: live columns of X (the rest is zero padding)
 // dW[128][ldw] += A^T . actB(B), dbias += colsum(A)     (A, B bf16 [R][128])
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,

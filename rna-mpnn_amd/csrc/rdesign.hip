@@ -401,10 +401,10 @@ struct RdWs {
     float *coords_p, *frame, *node_raw, *edge_raw, *hV, *hV2, *hE, *E1, *E2, *pq, *dh, *dA, *dB, *logits;
     size_t total;
 };
-static size_t rd_carve(const rdesign_ctx* c, int B, size_t Nmax, char* base, RdWs* w) {
+static size_t rd_carve(const rdesign_ctx* c, int B, size_t Nmax, char* base, RdWs* w, bool edges = true) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return base ? base + o : (char*)nullptr; };
-    const size_t K = c->cfg.k_neighbors, E = Nmax * K, D = c->cfg.dim_dense_layers > c->cfg.readout_hidden_dim ? c->cfg.dim_dense_layers : c->cfg.readout_hidden_dim;
+    const size_t K = c->cfg.k_neighbors, E = edges ? Nmax * K : 0, D = c->cfg.dim_dense_layers > c->cfg.readout_hidden_dim ? c->cfg.dim_dense_layers : c->cfg.readout_hidden_dim;
     RdWs tmp;
     RdWs& r = w ? *w : tmp;
     r.len = (int*)take(B * sizeof(int)); r.cu = (int*)take((B + 1) * sizeof(int)); r.node_b = (int*)take(Nmax * sizeof(int));
@@ -419,13 +419,17 @@ static size_t rd_carve(const rdesign_ctx* c, int B, size_t Nmax, char* base, RdW
     r.total = off;
     return off;
 }
+extern "C" size_t rdesign_readout_workspace_bytes(rdesign_handle h, int32_t n_rows) {
+    if (!h || n_rows <= 0) return 0;
+    return rd_carve(h, 1, (size_t)n_rows, nullptr, nullptr, false);
+}
 extern "C" size_t rdesign_workspace_bytes(rdesign_handle h, int32_t B, int32_t T) {
     if (!h || B <= 0 || T <= 0) return 0;
     return rd_carve(h, B, (size_t)B * T, nullptr, nullptr);
 }
 
 namespace {
-struct RdRun { rdesign_ctx* c; PackInfo pk; RdWs w; hipStream_t s; bool mixed; TDrop nodrop; int K;
+struct RdRun { rdesign_ctx* c; PackInfo pk; RdWs w; hipStream_t s; bool mixed; TDrop nodrop; int K; bool bad = false;
     TRows rn() const { return TRows{pk.cu + pk.B, 1, pk.Nmax}; }
     TRows re() const { return TRows{pk.cu + pk.B, K, pk.Nmax * K}; } };
 // Y = [beta Y] + act(X)[:, 0:Kc] . W[:, k0:k0+Kc]^T + bias        (act = GELU of the stored pre-activation when `gelu_in`)
@@ -489,14 +493,14 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
             tb16* Pt = reinterpret_cast<tb16*>(w.pq);
             tb16* Qt = Pt + (Nmax + 1) * RD_H;
             const float* w0 = rdp(c, L.msg[0].w);                                                            // [128][384] = [W_e | W_centre | W_neighbour]
-            te_gemm(r.rn(), w.hV, false, RD_H, w0 + RD_H, 3 * RD_H, true, rdp(c, L.msg[0].b), Pt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
-            te_gemm(r.rn(), w.hV, false, RD_H, w0 + 2 * RD_H, 3 * RD_H, true, nullptr, Qt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
+            r.bad |= !te_gemm(r.rn(), w.hV, false, RD_H, w0 + RD_H, 3 * RD_H, true, rdp(c, L.msg[0].b), Pt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
+            r.bad |= !te_gemm(r.rn(), w.hV, false, RD_H, w0 + 2 * RD_H, 3 * RD_H, true, nullptr, Qt, 0, false, nullptr, nullptr, r.nodrop, 0u, s);
             EFuse f{Pt, Qt, w.nbr, K, (int)Nmax, nullptr, nullptr, 0u};
             tb16* cur = reinterpret_cast<tb16*>(w.E1);
             tb16* nxt = reinterpret_cast<tb16*>(w.E2);
-            te_gemm(r.re(), w.hE, true, RD_H, w0, 3 * RD_H, true, nullptr, cur, 0, false, nullptr, &f, r.nodrop, 0u, s);
+            r.bad |= !te_gemm(r.re(), w.hE, true, RD_H, w0, 3 * RD_H, true, nullptr, cur, 0, false, nullptr, &f, r.nodrop, 0u, s);
             for (size_t i = 1; i < L.msg.size(); ++i) {
-                te_gemm(r.re(), cur, true, RD_H, rdp(c, L.msg[i].w), RD_H, true, rdp(c, L.msg[i].b), nxt, 0, true, nullptr, nullptr, r.nodrop, 0u, s);
+                r.bad |= !te_gemm(r.re(), cur, true, RD_H, rdp(c, L.msg[i].w), RD_H, true, rdp(c, L.msg[i].b), nxt, 0, true, nullptr, nullptr, r.nodrop, 0u, s);
                 tb16* t = cur; cur = nxt; nxt = t;
             }
             hipLaunchKernelGGL(k_rd_segsum_b, dim3((unsigned)((Nmax + 3) / 4)), dim3(256), 0, s, r.pk, K, w.nbr, cur, 1.0f / 30.0f, w.dh);
@@ -538,6 +542,7 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
             x = dst; ld = c->readout[i].out;
         }
     }
+    if (r.bad) return rd_fail(RDESIGN_ERR_UNSUPPORTED, "bf16 path: a GEMM variant this configuration needs is not built");
     if (h_V) RD_TRY(hipMemcpyAsync(h_V, w.hV, Nmax * RD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (logits) RD_TRY(hipMemcpyAsync(logits, w.logits, Nmax * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
     RD_TRY(hipGetLastError());
@@ -549,11 +554,11 @@ __global__ void k_rd_seti(int* p, int v) { *p = v; }
 extern "C" int rdesign_readout(rdesign_handle h, const float* h_V, int32_t n_rows, float* logits, void* ws, size_t ws_bytes, void* stream) {
     if (!h || !h_V || !logits || !ws || n_rows <= 0) return rd_fail(RDESIGN_ERR_BAD_ARG, "rdesign_readout: null pointer or non-positive row count");
     if (!h->arena || !h->finalized) return rd_fail(RDESIGN_ERR_WEIGHTS, "weights not set / not finalized");
-    if (ws_bytes < rd_carve(h, 1, (size_t)n_rows, nullptr, nullptr)) return rd_fail(RDESIGN_ERR_WORKSPACE, "workspace too small");
+    if (ws_bytes < rd_carve(h, 1, (size_t)n_rows, nullptr, nullptr, false)) return rd_fail(RDESIGN_ERR_WORKSPACE, "workspace too small");
     if (((uintptr_t)ws & 255) != 0) return rd_fail(RDESIGN_ERR_BAD_ARG, "workspace must be 256-byte aligned");
     RdRun r;
     r.c = h; r.s = (hipStream_t)stream; r.mixed = h->cfg.precision == RDESIGN_PREC_BF16; r.nodrop = TDrop{0ull, 0u, 1.f}; r.K = h->cfg.k_neighbors;
-    rd_carve(h, 1, (size_t)n_rows, (char*)ws, &r.w);
+    rd_carve(h, 1, (size_t)n_rows, (char*)ws, &r.w, false);
     r.pk.len = r.w.len; r.pk.cu = r.w.cu; r.pk.node_b = r.w.node_b; r.pk.B = 1; r.pk.T = n_rows; r.pk.Nmax = n_rows; r.pk.packed_in = 0;
     hipLaunchKernelGGL(k_rd_seti, dim3(1), dim3(1), 0, r.s, r.w.cu + 1, (int)n_rows);
     const float* x = h_V;

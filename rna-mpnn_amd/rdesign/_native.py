@@ -27,6 +27,7 @@ SYMBOLS = {
     "rdesign_use_weight_arena": (C.c_int, [_VP, _VP, _VP]),
     "rdesign_finalize_weights": (C.c_int, [_VP, _VP]),
     "rdesign_workspace_bytes": (_SZ, [_VP, _I32, _I32]),
+    "rdesign_readout_workspace_bytes": (_SZ, [_VP, _I32]),
     "rdesign_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "rdesign_readout": (C.c_int, [_VP, _VP, _I32, _VP, _VP, _SZ, _VP]),
 }

@@ -148,8 +148,10 @@ class RNAModel(nn.Module):
             self._sig = sig
         return dev
 
-    def _ws_args(self, B: int, T: int, dev):
-        need = int(_native.lib().rdesign_workspace_bytes(self._handle.ptr, B, T))
+    def _ws_args(self, B: int, T: int, dev, readout_rows: int = 0):
+        lib = _native.lib()
+        need = int(lib.rdesign_readout_workspace_bytes(self._handle.ptr, readout_rows) if readout_rows
+                   else lib.rdesign_workspace_bytes(self._handle.ptr, B, T))
         if self._ws is None or self._ws.numel() < need + 256 or self._ws.device != dev:
             self._ws = None
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
@@ -201,7 +203,7 @@ class RNAModel(nn.Module):
             raise ValueError(f"res_embedding must be (N, 128), N > 0; got {tuple(x.shape)}")
         n = int(x.shape[0])
         logits = torch.empty(n, 4, device=dev)
-        ws, ws_bytes = self._ws_args(1, n, dev)
+        ws, ws_bytes = self._ws_args(1, n, dev, readout_rows=n)
         with torch.cuda.device(dev):
             _native.check(_native.lib().rdesign_readout(self._handle.ptr, C.c_void_p(x.data_ptr()), n, C.c_void_p(logits.data_ptr()),
                                                         ws, ws_bytes, _stream(dev)))

@@ -617,3 +617,31 @@ def test_bf16_fast_path_tracks_f32_path_across_neighbourhood_sizes(k):
     assert torch.isfinite(b).all()
     assert (a - b).abs().max() < BF16_LOGIT_TOL, float((a - b).abs().max())
     assert (b * (1 - m).unsqueeze(-1) == 0).all()
+
+
+@pytest.mark.gpu
+def test_bf16_mixed_training_depth1_mlps_track_f32():
+    """The depth-1 variants of the per-edge MLPs and of the edge embedding (first Linear + P + Q [+ edge update] in ONE epilogue, no
+    second Linear) go through their own instantiations of the bf16-storage edge GEMM: gradients vs the exact-f32 path."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    coords, mask, labels = synth.synth_batch([40, 33, 57, 21], first_index=11)
+    c, m, y = torch.from_numpy(coords), torch.from_numpy(mask), torch.from_numpy(labels)
+    hp = dict(num_res_neighbours=12, num_res_mpnn_layers=3, padding_len=64, depth_res_mpnn=1, num_mpnn_edge_layers=1, depth_res_edge_feature=1)
+    torch.manual_seed(5)
+    exact = RNAMPNN(precision="f32", **hp).to("cuda:0").train()
+    mixed = RNAMPNN(precision="f32", **hp).to("cuda:0").train()      # (the bf16 INFERENCE kernels need depth 2; the trainer does not)
+    mixed.train_precision = "bf16"
+    mixed.load_state_dict(exact.state_dict())
+    l32 = exact.loss_and_grad(y, c, m, dropout=0.3, seed=7)
+    l16 = mixed.loss_and_grad(y, c, m, dropout=0.3, seed=7)
+    assert abs(float(l32) - float(l16)) < 5e-3
+    n_big = 0
+    for (k32, p32), (k16, p16) in zip(exact.named_parameters(), mixed.named_parameters()):
+        a, b = p32.grad.flatten().double(), p16.grad.flatten().double()
+        if float(a.norm()) < 1e-7 or a.numel() < 128:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.995, f"{k16}: cos {cos:.5f}"
+        n_big += 1
+    assert n_big > 30
