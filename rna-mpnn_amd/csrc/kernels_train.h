@@ -102,3 +102,4 @@ void t_wimg_destroy(WImageCache* c);
 void t_wimg_bind(WImageCache* c);            // null: kernels build their images themselves
 void t_wimg_clear(WImageCache* c);           // the weights moved (new arena)
 void t_wimg_refresh(WImageCache* c, hipStream_t s);
+int t_wimg_pending(const WImageCache* c);     // blocks registered since the last refresh (their kernels still build their own image)

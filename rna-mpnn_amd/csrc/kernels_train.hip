@@ -860,6 +860,7 @@ void t_wimg_destroy(WImageCache* c) {
     delete c;
 }
 void t_wimg_bind(WImageCache* c) { g_wimg = c; }
+int t_wimg_pending(const WImageCache* c) { return c ? (int)c->host.size() - c->built : 0; }
 void t_wimg_clear(WImageCache* c) { if (c) { c->host.clear(); c->synced = 0; c->built = 0; } }
 void t_wimg_refresh(WImageCache* c, hipStream_t s) {
     if (!c || c->host.empty()) return;

@@ -303,6 +303,8 @@ struct rdesign_ctx {
     float* arena = nullptr;          // caller's flat parameter buffer
     float* der = nullptr;
     bool finalized = false;
+    WImageCache* wimg = nullptr;     // prebuilt bf16 fragment images of the 128 x 128 weight blocks (bf16 path; kernels_train.h)
+    bool wimg_fresh = false;         // images match the weights (reset by finalize)
     RdLin node_emb, edge_emb;
     int nn_g, nn_b, ne_g, ne_b;
     std::vector<RdLayer> layers;
@@ -361,6 +363,7 @@ extern "C" int rdesign_create(const RDesignConfig* cfg, rdesign_handle* out) {
 extern "C" int rdesign_destroy(rdesign_handle h) {
     if (!h) return RDESIGN_OK;
     if (h->der) (void)hipFree(h->der);
+    t_wimg_destroy(h->wimg);
     delete h;
     return RDESIGN_OK;
 }
@@ -376,6 +379,7 @@ extern "C" int rdesign_weight_info(rdesign_handle h, int32_t i, const char** key
 extern "C" int rdesign_use_weight_arena(rdesign_handle h, float* arena, void* stream) {
     if (!h || !arena || ((uintptr_t)arena & 15)) return rd_fail(RDESIGN_ERR_BAD_ARG, "rdesign_use_weight_arena: null or unaligned arena");
     h->arena = arena;
+    t_wimg_clear(h->wimg);
     if (!h->der) {
         RD_TRY(hipMalloc((void**)&h->der, h->der_floats * sizeof(float)));
         RD_TRY(hipMemsetAsync(h->der, 0, h->der_floats * sizeof(float), (hipStream_t)stream));
@@ -392,6 +396,7 @@ extern "C" int rdesign_finalize_weights(rdesign_handle h, void* stream) {
     for (auto& l : h->readout) tr(l);
     RD_TRY(hipGetLastError());
     h->finalized = true;
+    h->wimg_fresh = false;
     return RDESIGN_OK;
 }
 
@@ -464,6 +469,11 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
     RdWs& w = r.w;
     hipStream_t s = r.s;
     r.pk.len = w.len; r.pk.cu = w.cu; r.pk.node_b = w.node_b; r.pk.B = B; r.pk.T = T; r.pk.Nmax = (int)Nmax; r.pk.packed_in = 0;
+    if (r.mixed) {      // weights are static between finalize calls: the images are rebuilt once, blocks first seen in this call build their own
+        if (!c->wimg) c->wimg = t_wimg_create(256);
+        if (c->wimg && (!c->wimg_fresh || t_wimg_pending(c->wimg) > 0)) { t_wimg_refresh(c->wimg, s); c->wimg_fresh = true; }
+        t_wimg_bind(c->wimg);
+    }
     launch_lengths(mask, r.pk, s);
     ZeroRegions z{};
     z.ptr[0] = w.hV + Nmax * RD_H; z.words[0] = RD_H; z.ptr[1] = w.hV2 + Nmax * RD_H; z.words[1] = RD_H;
@@ -542,6 +552,7 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
             x = dst; ld = c->readout[i].out;
         }
     }
+    t_wimg_bind(nullptr);
     if (r.bad) return rd_fail(RDESIGN_ERR_UNSUPPORTED, "bf16 path: a GEMM variant this configuration needs is not built");
     if (h_V) RD_TRY(hipMemcpyAsync(h_V, w.hV, Nmax * RD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (logits) RD_TRY(hipMemcpyAsync(logits, w.logits, Nmax * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));

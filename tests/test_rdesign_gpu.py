@@ -106,3 +106,17 @@ def test_large_batch_properties():
     assert torch.equal(a["logits"], b["logits"])
     # every row is LayerNorm output: mean 0 / variance 1 under the affine (gain ~ 1 +- 0.1 here) - a cheap global sanity bound
     assert a["h_V"].abs().max() < 20
+
+
+def test_weight_update_reaches_the_cached_weight_images():
+    """bf16 path: the GEMM kernels read prebuilt fragment images of the weights; a `load_state_dict` after a forward must rebuild them."""
+    kw = dict(k_neighbors=6, num_mpnn_layers=2)
+    m, cfg, sd = _model(kw, "bf16", seed=0)
+    X, mask = _batch([12, 9], seed=5)
+    a = m._run(X, mask, want=("logits",))["logits"].clone()
+    m._run(X, mask, want=("logits",))                              # second call: every image comes from the cache
+    sd2 = _weights(cfg, seed=1)
+    m.load_state_dict(sd2)
+    b = m._run(X, mask, want=("logits",))["logits"]
+    ref = O.forward(X, mask, sd2, cfg)[1]
+    assert (b.cpu() - ref).abs().max() < 5e-2 and (a - b).abs().max() > 1e-2
