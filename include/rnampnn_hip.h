@@ -218,6 +218,13 @@ int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches,
 const char* rnampnn_last_error(void);
 const char* rnampnn_version(void);
 
+/* Test tap of the 90 raw edge features of ResFeature (rnampnn/model/feature.py:386-517: `_cross_dists` 49, `_cross_angles` 25,
+ * `_cross_dihedrals` 16) - the tensor the inference kernels keep in registers.  feats (B,T,k,96) f32: columns 90..95, padded residues and
+ * absent neighbour slots are zero (the reference holds 1e6 distances there); edge_index (B,T,k) i64 optional. */
+size_t rnampnn_edge_raw_workspace_bytes(rnampnn_handle h, int32_t B, int32_t T);
+int rnampnn_edge_raw_features(rnampnn_handle h, const float* coords, const float* mask, int32_t B, int32_t T, int64_t* edge_index,
+                              float* feats, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Gradient-boosted-tree read-out (PARITY UNPINNED: xgboost is not installed, no fitted model ships).
  * Replaces `self.xgb_readout.predict(embedding)` (rnampnn/model/rnampnn.py:136-145,297-298) for a fitted `multi:softmax` gbtree model
  * given as the arrays of XGBoost's JSON model format (`learner.gradient_booster.model.trees[*].{left_children,right_children,

@@ -191,6 +191,25 @@ class RNAMPNN(NativeModule):
                                                      C.c_size_t(self._ws.numel() - (aligned - base)), _stream(device)))
         return (logits, emb) if want_embedding else logits
 
+    @torch.no_grad()
+    def raw_edge_features(self, coords: torch.Tensor, mask: torch.Tensor):
+        """-> (feats (B,T,k,90), edge_index (B,T,k)): the raw edge features of ``ResFeature`` (``feature.py:386-517``: cross distances,
+        bond-angle and dihedral-normal dot products) - a parity tap; zero on padded residues and absent neighbour slots."""
+        device = self._ensure()
+        c, m = _prep(coords, device), _prep(mask, device)
+        B, T, k = int(c.shape[0]), int(c.shape[1]), int(self._hp["num_res_neighbours"])
+        lib = _native.lib()
+        need = int(lib.rnampnn_edge_raw_workspace_bytes(self._handle.ptr, B, T))
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+        base = ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        feats = torch.empty(B, T, k, 96, dtype=torch.float32, device=device)
+        idx = torch.empty(B, T, k, dtype=torch.int64, device=device)
+        with torch.cuda.device(device):
+            _native.check(lib.rnampnn_edge_raw_features(self._handle.ptr, _ptr(c), _ptr(m), B, T, _ptr(idx), _ptr(feats),
+                                                        C.c_void_p(aligned), C.c_size_t(need), _stream(device)))
+        return feats[..., :90], idx
+
     def forward_taps(self, coords, mask, names, tap_layer: int = 0, T_norm: int = 0):
         """Forward with intermediate tensors (parity tests): ``names`` from edge_index, raw, h0, e0,
         h_layer, e_layer, h_post, raw_emb; ``tap_layer`` is the 1-based ResMPNN layer of h_/e_layer."""

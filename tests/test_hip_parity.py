@@ -645,3 +645,23 @@ def test_bf16_mixed_training_depth1_mlps_track_f32():
         assert cos > 0.995, f"{k16}: cos {cos:.5f}"
         n_big += 1
     assert n_big > 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_raw_edge_features_match_reference_golden(golden, name):
+    """Rows A3 / A4 pinned directly: the 90 raw edge features (49 cross distances, 25 bond-angle and 16 dihedral-normal dot products,
+    feature.py:386-517) of the first residues of every RNA against the `edge_raw` the REFERENCE modules produced (tools/gen_golden.py) -
+    not only through e0.  Edges the reference marks with its 1e6 distance (absent neighbours, padded residues) are zero here and excluded."""
+    arrs, hp, shapes = golden(name)
+    model, _ = _model(hp, shapes, "f32")
+    coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
+    feats, idx = model.raw_edge_features(coords, mask)
+    ref = arrs["edge_raw"]                                       # (B, first nodes, k, 90)
+    en = ref.shape[1]
+    got = feats[:, :en].cpu().numpy()
+    valid = (ref[..., :49].max(-1) < 1e5) & (arrs["mask"][:, :en, None] > 0)
+    assert valid.sum() > 0
+    assert np.allclose(got[valid][:, :49], ref[valid][:, :49], rtol=2e-5, atol=2e-4), name      # distances (Angstrom)
+    assert np.abs(got[valid][:, 49:] - ref[valid][:, 49:]).max() < 2e-4, name                   # dot products of unit vectors
+    assert (got[~valid] == 0).all()
