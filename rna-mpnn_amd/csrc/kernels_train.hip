@@ -1650,24 +1650,27 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
 }
 
 // ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
+// One wave per residue, lane = two adjacent channels.  The k validity flags are taken in ONE load + ballot (a per-slot `if (nbr >= 0)` in the
+// loop is a dependent load -> branch -> load chain per slot: 83 % of the wave cycles were waits), the row loads are unconditional and go
+// out in batches of the unrolled loop.
 __global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const tb16* __restrict__ pre2,
                                                    const float* __restrict__ hin, float* __restrict__ out, TDrop dr, unsigned site) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
-    const int c = 2 * (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63, c = 2 * lane;
     const unsigned key = drop_key(dr, site);
+    const unsigned long long vm = __ballot(lane < k && nbr[(size_t)p * k + (lane < k ? lane : 0)] >= 0);
+    const int cnt = __popcll(vm);
+    const tb16* base = pre2 + (size_t)p * k * RN_D + c;
     float s0 = 0.f, s1 = 0.f;
-    int cnt = 0;
+#pragma unroll 6
     for (int sl = 0; sl < k; ++sl) {
-        const size_t er = (size_t)p * k + sl;
-        if (nbr[er] >= 0) {
-            const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
-            float m0, m1;
-            drop_pair(dr, key, (unsigned)er * 64u + (c >> 1), m0, m1);
-            s0 += gelu_fast(tbf_lo(w)) * m0;
-            s1 += gelu_fast(tbf_hi(w)) * m1;
-            ++cnt;
-        }
+        const unsigned w = *reinterpret_cast<const unsigned*>(base + (size_t)sl * RN_D);
+        float m0, m1;
+        drop_pair(dr, key, (unsigned)(p * k + sl) * 64u + lane, m0, m1);
+        const bool valid = (vm >> sl) & 1ull;               // (a select, not a multiply by 0: an absent slot's row may hold anything)
+        s0 += valid ? gelu_fast(tbf_lo(w)) * m0 : 0.f;
+        s1 += valid ? gelu_fast(tbf_hi(w)) * m1 : 0.f;
     }
     const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
     const tf32x2 hv = *reinterpret_cast<const tf32x2*>(hin + (size_t)p * RN_D + c);
@@ -1677,21 +1680,23 @@ __global__ void __launch_bounds__(256) k_eseg_mean_bwd(PackInfo pk, int k, const
                                                        const tb16* __restrict__ pre2, tb16* __restrict__ dpre2, TDrop dr, unsigned site) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
-    const int c = 2 * (threadIdx.x & 63);
-    int cnt = 0;
-    for (int sl = 0; sl < k; ++sl) cnt += nbr[(size_t)p * k + sl] >= 0;
+    const int lane = threadIdx.x & 63, c = 2 * lane;
+    const unsigned key = drop_key(dr, site);
+    const unsigned long long vm = __ballot(lane < k && nbr[(size_t)p * k + (lane < k ? lane : 0)] >= 0);
+    const int cnt = __popcll(vm);
     const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
     const tf32x2 g = *reinterpret_cast<const tf32x2*>(dagg + (size_t)p * RN_D + c);
+    const float g0 = g[0] * inv, g1 = g[1] * inv;
+    const tb16* base = pre2 + (size_t)p * k * RN_D + c;
+    tb16* obase = dpre2 + (size_t)p * k * RN_D + c;
+#pragma unroll 6
     for (int sl = 0; sl < k; ++sl) {
-        const size_t er = (size_t)p * k + sl;
-        unsigned o = 0u;
-        if (nbr[er] >= 0) {
-            const unsigned w = *reinterpret_cast<const unsigned*>(pre2 + er * RN_D + c);
-            float m0, m1;
-            drop_pair(dr, drop_key(dr, site), (unsigned)er * 64u + (c >> 1), m0, m1);
-            o = tpack2(g[0] * inv * gelu_d_fast(tbf_lo(w)) * m0, g[1] * inv * gelu_d_fast(tbf_hi(w)) * m1);
-        }
-        *reinterpret_cast<unsigned*>(dpre2 + er * RN_D + c) = o;
+        const unsigned w = *reinterpret_cast<const unsigned*>(base + (size_t)sl * RN_D);
+        float m0, m1;
+        drop_pair(dr, key, (unsigned)(p * k + sl) * 64u + lane, m0, m1);
+        const bool valid = (vm >> sl) & 1ull;
+        const unsigned o = tpack2(g0 * gelu_d_fast(tbf_lo(w)) * m0, g1 * gelu_d_fast(tbf_hi(w)) * m1);
+        *reinterpret_cast<unsigned*>(obase + (size_t)sl * RN_D) = valid ? o : 0u;
     }
 }
 void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s) {

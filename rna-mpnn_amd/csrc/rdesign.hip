@@ -280,14 +280,17 @@ __global__ void __launch_bounds__(256) k_rd_segsum_b(PackInfo pk, int K, const i
                                                      float* __restrict__ out) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
-    const int c = 2 * (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63, c = 2 * lane;
+    // validity of the K slots in one load + ballot (K <= 64), then unconditional row loads in batches
+    const unsigned long long vm = __ballot(lane < K && nbr[(size_t)p * K + (lane < K ? lane : 0)] >= 0);
+    const tb16* base = pre + (size_t)p * K * RD_H + c;
     float s0 = 0.f, s1 = 0.f;
+#pragma unroll 5
     for (int sl = 0; sl < K; ++sl) {
-        const size_t er = (size_t)p * K + sl;
-        if (nbr[er] >= 0) {
-            const unsigned w = *reinterpret_cast<const unsigned*>(pre + er * RD_H + c);
-            s0 += gelu_e(__uint_as_float(w << 16)); s1 += gelu_e(__uint_as_float(w & 0xffff0000u));
-        }
+        const unsigned w = *reinterpret_cast<const unsigned*>(base + (size_t)sl * RD_H);
+        const bool valid = (vm >> sl) & 1ull;
+        s0 += valid ? gelu_e(__uint_as_float(w << 16)) : 0.f;
+        s1 += valid ? gelu_e(__uint_as_float(w & 0xffff0000u)) : 0.f;
     }
     out[(size_t)p * RD_H + c] = s0 * inv_scale; out[(size_t)p * RD_H + c + 1] = s1 * inv_scale;
 }
