@@ -1092,6 +1092,9 @@ static int mm128_grid(const TRows& rows) {
 static bool mm_ok(const void* X, int ldx, int K, const void* W, int ldw, bool b_rows) {
     return K % 16 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && (!b_rows || (ldw % 4 == 0 && ((uintptr_t)W & 15) == 0));
 }
+// LDS-tiled general GEMM (defined below, next to the transposed-read helper): false when the shape is not covered
+static bool launch_tmm(bool wt, const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s);
 // Y = [beta Y] + actA(X) . W^T + bias            (W [N][K] row-major: nn.Linear.weight as it is stored)
 bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
                 int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s) {
@@ -1101,6 +1104,7 @@ bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* 
                            actA ? 1 : 0, (const float*)nullptr, dr, site, wimg_lookup(W, ldw, true, 0));
         return true;
     }
+    if (launch_tmm(false, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA, nullptr, 0, dr, site, s)) return true;
     // 64-row wave tiles reuse the B fragments twice; with few rows (node tensors) 32-row tiles fill more of the chip
     const bool small = (long long)((rows.maxrows + 255) / 256) * ((N + 127) / 128) < 2 * rn_num_cus();
     if (small) {
@@ -1123,6 +1127,7 @@ bool tm_gemm_nn(const TRows& rows, const float* X, int ldx, int K, const float* 
                            epi_pre, dr, site, wimg_lookup(W, ldw, false, 0));
         return true;
     }
+    if (launch_tmm(true, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, false, epi_pre, ld_epi, dr, site, s)) return true;
     const bool small = (long long)((rows.maxrows + 255) / 256) * ((N + 127) / 128) < 2 * rn_num_cus();
     if (small) {
         dim3 grid((rows.maxrows + 127) / 128, (N + 127) / 128);
@@ -1151,6 +1156,158 @@ __device__ __forceinline__ tu32x4 tr_frag(const unsigned short* tile, int row0, 
     const tu32x2 l2 = __builtin_bit_cast(tu32x2, lo), h2 = __builtin_bit_cast(tu32x2, hi);
     return tu32x4{l2[0], l2[1], h2[0], h2[1]};
 }
+// ---- LDS-tiled NT / NN for the node-level shapes (K or N = 256 .. 512): a (64 MT) x 128 tile per workgroup (2 x 2 waves), K staged in
+// steps of 64 with the next tile's global loads in flight.  X tile: f32 rows -> [GELU + dropout] -> bf16, k-contiguous in LDS.  W tile:
+// NT (W [N][K]): k-contiguous rows like X, plain 16-byte fragment reads;  NN (W [K][N], the backward's dX = dY . W): the tile is stored as
+// it is read, [k][n], and the B fragments come out of ds_read_b64_tr_b16 (k runs down the rows: the transposed read of k_mm_tn).
+// Fragments straight from global memory (k_mm) re-read every operand once per wave: 768 B per MFMA against 256 B here.
+#define TM_LD 72                                              // bf16 elements per k-contiguous LDS row (64 data + 8 pad)
+template <bool WT, int MT>
+__global__ void __launch_bounds__(256) k_tmm(TRows rows, const float* __restrict__ X, int ldx, int K, const float* __restrict__ W, int ldw,
+        const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
+        int ld_epi, TDrop dr, unsigned site) {
+    constexpr int BM = 64 * MT;
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM * TM_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[WT ? 64 * TN_PITCH : 128 * TM_LD];
+    const int R = nrows(rows);
+    const int row0 = blockIdx.x * BM;
+    if (row0 >= R) return;
+    const int col0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    tf32x16 acc[MT][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // staging maps.  A: thread -> (row tid / (4 / MT) ..., 16 * MT floats);  B (NT): (n = tid >> 1, 32 floats);  B (NN): (k = tid >> 2, 32 floats of n)
+    constexpr int AV = 4 * MT;                                // float4 loads of A per thread: BM * 64 / 256 / 4
+    const int arow = MT == 2 ? tid >> 1 : tid >> 2, acol = MT == 2 ? (tid & 1) * 32 : (tid & 3) * 16;
+    tf32x4 ar[AV], br[8];
+    const unsigned key = drop_key(dr, site);
+    auto load_tile = [&](int k0) {
+        const int row = row0 + arow, kk = k0 + acol;
+        const float* src = X + (size_t)(row < R ? row : R - 1) * ldx + (kk < K ? kk : 0);
+#pragma unroll
+        for (int v = 0; v < AV; ++v) ar[v] = *reinterpret_cast<const tf32x4*>(src + 4 * v);
+        if (!WT) {
+            const int n = col0 + (tid >> 1), kb = k0 + (tid & 1) * 32;
+            const float* ws = W + (size_t)(n < N ? n : 0) * ldw + (kb < K ? kb : 0);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) br[v] = *reinterpret_cast<const tf32x4*>(ws + 4 * v);
+        } else {
+            const int k = k0 + (tid >> 2), nb = col0 + (tid & 3) * 32;
+            const float* ws = W + (size_t)(k < K ? k : 0) * ldw + (nb + 31 < N ? nb : 0);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) br[v] = *reinterpret_cast<const tf32x4*>(ws + 4 * v);
+        }
+    };
+    auto store_tile = [&](int k0) {
+        typedef __attribute__((ext_vector_type(2))) unsigned tu32x2;
+        {
+            const int row = row0 + arow, kk = k0 + acol;
+            const bool ok = row < R && kk < K;
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                float x[4] = {ar[v][0], ar[v][1], ar[v][2], ar[v][3]};
+                if (actA) {
+                    float m0, m1, m2, m3;
+                    const unsigned P = (unsigned)(((unsigned long long)row * K + kk + 4 * v) >> 1);
+                    drop_pair(dr, key, P, m0, m1); drop_pair(dr, key, P + 1, m2, m3);
+                    x[0] = gelu_fast(x[0]) * m0; x[1] = gelu_fast(x[1]) * m1; x[2] = gelu_fast(x[2]) * m2; x[3] = gelu_fast(x[3]) * m3;
+                }
+                const tu32x2 w = ok ? tu32x2{tpack2(x[0], x[1]), tpack2(x[2], x[3])} : tu32x2{0u, 0u};
+                *reinterpret_cast<tu32x2*>(As + arow * TM_LD + acol + 4 * v) = w;
+            }
+        }
+        if (!WT) {
+            const int n = col0 + (tid >> 1), kb = k0 + (tid & 1) * 32;
+            const bool ok = n < N && kb < K;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const tu32x2 w = ok ? tu32x2{tpack2(br[v][0], br[v][1]), tpack2(br[v][2], br[v][3])} : tu32x2{0u, 0u};
+                *reinterpret_cast<tu32x2*>(Bs + (tid >> 1) * TM_LD + (tid & 1) * 32 + 4 * v) = w;
+            }
+        } else {
+            const int k = k0 + (tid >> 2), nb = col0 + (tid & 3) * 32;
+            const bool ok = k < K && nb + 31 < N;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const tu32x2 w = ok ? tu32x2{tpack2(br[v][0], br[v][1]), tpack2(br[v][2], br[v][3])} : tu32x2{0u, 0u};
+                *reinterpret_cast<tu32x2*>(Bs + (tid >> 2) * TN_PITCH + (tid & 3) * 32 + 4 * v) = w;
+            }
+        }
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();
+        store_tile(k0);
+        __syncthreads();
+        if (k0 + 64 < K) load_tile(k0 + 64);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tu32x4 af[MT], bf[2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const tu32x4*>(As + (32 * MT * wr + 32 * a + r) * TM_LD + 16 * ks + 8 * h);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (!WT) bf[b] = *reinterpret_cast<const tu32x4*>(Bs + (64 * wc + 32 * b + r) * TM_LD + 16 * ks + 8 * h);
+                else bf[b] = tr_frag(Bs, 16 * ks, 64 * wc + 32 * b, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + 64 * wc + 32 * b + r;
+        const bool colok = col < N;
+        const int cc = colok ? col : 0;
+        const float bv = (bias && colok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int rbase = row0 + 32 * MT * wr + 32 * a + 4 * h;
+            float yo[16], pr[16];
+            if (beta) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) yo[i] = Y[(size_t)min(rbase + (i & 3) + 8 * (i >> 2), R - 1) * ldy + cc];
+            }
+            if (epi_pre) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pr[i] = epi_pre[(size_t)min(rbase + (i & 3) + 8 * (i >> 2), R - 1) * ld_epi + cc];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = rbase + (i & 3) + 8 * (i >> 2);
+                float v = acc[a][b][i] + bv;
+                if (epi_pre) v *= gelu_d_fast(pr[i]) * drop_mul(dr, site, (unsigned long long)row * ld_epi + col);
+                if (beta) v += yo[i];
+                if (colok && row < R) Y[(size_t)row * ldy + col] = v;
+            }
+        }
+    }
+}
+static bool launch_tmm(bool wt, const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
+                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s) {
+    // 16-byte loads of 16 / 32 consecutive floats: K in whole half-tiles, aligned rows; NN: whole 32-column groups of W
+    if (K % 32 || ldx % 4 || ldw % 4 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || (wt && N % 32) || K < 64) return false;
+    const long long big = (long long)((rows.maxrows + 127) / 128) * ((N + 127) / 128);
+    if (big >= 2 * rn_num_cus()) {
+        dim3 grid((rows.maxrows + 127) / 128, (N + 127) / 128);
+        if (wt) hipLaunchKernelGGL((k_tmm<true, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+        else hipLaunchKernelGGL((k_tmm<false, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+    } else {
+        dim3 grid((rows.maxrows + 63) / 64, (N + 127) / 128);
+        if (wt) hipLaunchKernelGGL((k_tmm<true, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+        else hipLaunchKernelGGL((k_tmm<false, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restrict__ A, int lda, int M, const float* __restrict__ B,
         int ldb, int K, float* __restrict__ part, size_t pstride, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
     __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
