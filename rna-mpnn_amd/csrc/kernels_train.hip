@@ -1681,10 +1681,11 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
 // ---- TN with bf16 operands: dW[n][kk] += sum_m A[m][n] actB(B[m][kk]), M = K = 128.  Same scheme as k_mm_tn (64-row tiles row-major
 // in LDS, transposed fragment reads, row range split over blockIdx.z, ordered reduction of the partial tiles); the staging is a straight
 // 16-byte copy unless the activation prologue is on.
-__global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restrict__ A, const tb16* __restrict__ B, float* __restrict__ part,
+__global__ void __launch_bounds__(256, 3) k_emm_tn(TRows rows, const tb16* __restrict__ A, const tb16* __restrict__ B, float* __restrict__ part,
         size_t pstride, int rows_per_split, int actB, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+    // 40 KiB of LDS and <= 168 registers: three workgroups per CU, so that one's staging VALU (the activation) runs under the others' MFMAs
     __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
-    __shared__ float cs_red[16][128];
+    float (*cs_red)[128] = reinterpret_cast<float (*)[128]>(tA);      // [16][128] floats = 8 KiB: reuses the A tile after the last MFMAs
     const int R = nrows(rows);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1693,8 +1694,7 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
     const unsigned key = drop_key(dr, site);
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const tu32x4 z4 = {0u, 0u, 0u, 0u};
-    // raw tile loads, TWO tiles ahead of the MFMAs (a workgroup alone cannot cover the HBM latency with one); the activation
-    // prologue runs when the tile is moved to LDS
+    // raw tile loads one tile ahead of the MFMAs; the activation prologue runs when the tile is moved to LDS
     auto load_tile = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1752,17 +1752,12 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
                 for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
         }
     };
-    tu32x4 a0[4], b0[4], a1[4], b1[4];
+    tu32x4 a0[4], b0[4];
     int m0 = p_begin;
-    if (m0 < p_end) { load_tile(m0, a0, b0); load_tile(m0 + 64, a1, b1); }
+    if (m0 < p_end) load_tile(m0, a0, b0);
     while (m0 < p_end) {
         stage(m0, a0, b0);
-        load_tile(m0 + 128, a0, b0);
-        compute();
-        m0 += 64;
-        if (m0 >= p_end) break;
-        stage(m0, a1, b1);
-        load_tile(m0 + 128, a1, b1);
+        load_tile(m0 + 64, a0, b0);                           // next tile's loads fly under this tile's MFMAs (and the other two workgroups of the CU)
         compute();
         m0 += 64;
     }
@@ -1791,12 +1786,12 @@ __global__ void __launch_bounds__(256) k_emm_tn(TRows rows, const tb16* __restri
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
                 unsigned site, float* dbias, hipStream_t s, int cols_keep) {
     const size_t mk = 128 * 128;
-    long long cap = (long long)((sc.floats - (size_t)520 * 128) / mk) - 16;
+    long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
     int splits = (rows.maxrows + 1023) / 1024;
-    const int want = 2 * rn_num_cus();
+    const int want = 3 * rn_num_cus();                       // three resident workgroups per CU
     if (splits > want) splits = want;
     if (splits > cap) splits = (int)cap;
-    if (splits > 500) splits = 500;
+    if (splits > 768) splits = 768;
     if (splits < 1) splits = 1;
     const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
     const size_t pstride = mk + (dbias ? 128 : 0);
