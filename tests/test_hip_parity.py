@@ -665,3 +665,35 @@ def test_raw_edge_features_match_reference_golden(golden, name):
     assert np.allclose(got[valid][:, :49], ref[valid][:, :49], rtol=2e-5, atol=2e-4), name      # distances (Angstrom)
     assert np.abs(got[valid][:, 49:] - ref[valid][:, 49:]).max() < 2e-4, name                   # dot products of unit vectors
     assert (got[~valid] == 0).all()
+
+
+@pytest.mark.gpu
+def test_bf16_mixed_training_large_batch_tracks_f32():
+    """17 K nucleotides in one step: the node-level GEMMs take their 128-row block tiles (`k_tmm<., 2>`), the per-edge kernels their
+    multi-tile grid-stride loops and the weight-gradient reductions their two-level form - paths the small batches above do not reach."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    lens = synth.synth_lengths(136, 110, 140, seed=4)
+    coords, mask, labels = synth.synth_batch(lens, first_index=900)
+    assert int(mask.sum()) > 16500
+    c, m, y = torch.from_numpy(coords), torch.from_numpy(mask), torch.from_numpy(labels)
+    hp = dict(num_res_neighbours=30, num_res_mpnn_layers=2, padding_len=int(mask.shape[1]))
+    torch.manual_seed(8)
+    exact = RNAMPNN(precision="f32", **hp).to("cuda:0").train()
+    mixed = RNAMPNN(precision="bf16", **hp).to("cuda:0").train()
+    mixed.load_state_dict(exact.state_dict())
+    l32 = exact.loss_and_grad(y, c, m, dropout=0.4, seed=21)
+    l16 = mixed.loss_and_grad(y, c, m, dropout=0.4, seed=21)
+    assert abs(float(l32) - float(l16)) < 5e-3, (float(l32), float(l16))
+    n_big = 0
+    for (k32, p32), (k16, p16) in zip(exact.named_parameters(), mixed.named_parameters()):
+        a, b = p32.grad.flatten().double(), p16.grad.flatten().double()
+        if float(a.norm()) < 1e-7 or a.numel() < 128:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.995, f"{k16}: cos {cos:.5f}"
+        n_big += 1
+    assert n_big > 30
+    g = mixed.flat_grad.clone()
+    mixed.loss_and_grad(y, c, m, dropout=0.4, seed=21)
+    assert torch.equal(mixed.flat_grad, g)
