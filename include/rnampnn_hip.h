@@ -165,12 +165,14 @@ int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, i
                             int32_t n_samples, const uint64_t* seed_device, int8_t* out, void* stream);
 
 /* -- training ---------------------------------------------------------------------------- */
-/* The training surface of RNAMPNN (rnampnn.py:187-207 + Lightning's loss.backward()), f32 kernels:
+/* The training surface of RNAMPNN (rnampnn.py:187-207 + Lightning's loss.backward()):
  *   rnampnn_train_forward  - `self(coords, mask)` in train mode.  Dropout with probability `dropout` after every GELU
  *       (mpnn.py:140,150; feature.py:200; functional.py:69,124,184) and on the attention probabilities
  *       (nn.MultiheadAttention(dropout=...), functional.py:109).  The reference draws its masks from torch's global RNG;
- *       here the keep decision of an element is a pure function of (seed, site, element index) - a 64-bit counter hash
- *       restated by oracle/rnampnn_oracle.py - so a step is reproducible and testable against autograd.  The
+ *       here the keep decision of an element is a pure function of (seed, site, element index) - one 32-bit counter hash per
+ *       PAIR of elements, its low / high 16 bits deciding the even / odd one (csrc/kernels_train.h: TDrop), restated by
+ *       oracle/rnampnn_oracle.py - so a step is reproducible and testable against autograd.  A call accepts
+ *       B*T*k < 2^26 edge rows and B*T < 2^23 residues (32-bit pair indices); larger batches return RNAMPNN_ERR_BAD_ARG.  The
  *       activations the backward needs (the "tape") stay in `workspace`, which must be left untouched until
  *       rnampnn_train_backward has run.  logits (B,T,4) out.
  *   rnampnn_train_backward - gradient of every parameter from dlogits (B,T,4) = d loss / d logits of ANY loss the
@@ -188,7 +190,8 @@ int64_t rnampnn_grad_numel(rnampnn_handle h);
 int     rnampnn_weight_offset(rnampnn_handle h, int32_t i, int64_t* offset);
 #define RNAMPNN_TRAIN_F32        0  /* exact-f32 GEMMs: the parity-grade path (gradients vs oracle autograd to 2e-3)         */
 #define RNAMPNN_TRAIN_BF16_MIXED 1  /* the reference's `bf16-mixed` (rnampnn/utils/train.py:109): GEMM operands bf16 on MFMA, */
-                                    /* f32 accumulate, everything else f32                                                    */
+                                    /* f32 accumulate; as under autocast, every per-edge activation and its gradient is a bf16 */
+                                    /* tensor in HBM (the tape), node-sized tensors and all reductions stay f32                */
 int     rnampnn_train_forward(rnampnn_handle h, const float* coords, const float* mask, int32_t B, int32_t T,
                               int32_t T_norm, float dropout, uint64_t seed, int32_t flags, float* logits,
                               void* workspace, size_t workspace_bytes, void* stream);
