@@ -84,6 +84,12 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
 // dW[128][ldw] += A^T . actB(B), dbias += colsum(A)     (A, B bf16 [R][128])
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
                 unsigned site, float* dbias, hipStream_t s, int cols_keep = 128);      // cols_keep: live columns of B
+// fused pair of a first Linear's backward: dW += dY^T X, DE += dY . W   (one pass over dY)
+void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, const float* W, int ldw, float* dW, int ldw_out,
+                  const TScratch& sc, hipStream_t s);
+// fused pair of a depth-2 MLP's backward: dW += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask   (one pass over dY and PRE)
+void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
+                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s);
 void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s);
 void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);

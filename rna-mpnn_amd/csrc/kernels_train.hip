@@ -1801,6 +1801,287 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
     reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw, s, tmp, (int)mk, dbias, cols_keep);
 }
 
+// ---- the two kernels that consume d pre2 of a depth-2 per-edge MLP, fused: dW2 += dpre2^T a1, db2 += colsum(dpre2) (k_emm_tn with
+// the activation recomputed) AND d pre1 = (dpre2 . W2) * gelu'(pre1) * mask (k_emm128 epilogue form).  Separately they read dpre2 and pre1
+// twice and evaluate the dropout hash and the sigmoid of the GELU twice per element; here a 64-row tile of each is loaded once, ONE pass over
+// pre1 produces a1 = gelu * mask (the TN operand) and g' = gelu' * mask (an LDS tile for the NN epilogue), and the same dpre2 tile in LDS
+// feeds the transposed reads of the weight-gradient MFMAs and, as row-major fragments, the MFMAs of d pre1 (output transposed in the
+// accumulators as in k_emm128: lane = row, 16-byte stores).  W2's fragment image is staged through the LDS region that then holds g'.
+__device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d) {          // (gelu_fast(x), gelu_d_fast(x)) sharing the sigmoid
+    const float p = fmaf(x * x, -0.10012571f, -2.3087657f);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+    g = x * sg;
+    d = fmaf(x * 0.3989422804f, __builtin_amdgcn_exp2f(x * x * -0.72134752f), sg);
+}
+__global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __restrict__ dY, const tb16* __restrict__ PRE, tb16* __restrict__ DX,
+        const float* __restrict__ W, int ldw, const unsigned short* __restrict__ wimg, float* __restrict__ part, size_t pstride,
+        int rows_per_split, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+    __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short tG[32 * 64 * 8];          // W2 image (32 KiB) first, then the g' tile [64][TN_PITCH]
+    float (*cs_red)[128] = reinterpret_cast<float (*)[128]>(tA);
+    const int R = nrows(rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
+    const int ch = tid & 15, rg = tid >> 4;
+    const unsigned key = drop_key(dr, site);
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    // this wave's share of d pre1: rows 32 wr .. 32 wr + 31 of the tile, channel blocks 2 wc and 2 wc + 1
+    stage_wimage(tG, wimg, W, ldw, false, 1, tid);
+    __syncthreads();
+    tu32x4 wf[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wf[ks][u] = reinterpret_cast<const tu32x4*>(tG)[(ks * 4 + 2 * wc + u) * 64 + lane];
+    auto load_tile = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rg + 16 * i;
+            const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+            xa[i] = *reinterpret_cast<const tu32x4*>(dY + (size_t)mc * 128 + 8 * ch);
+            xb[i] = *reinterpret_cast<const tu32x4*>(PRE + (size_t)mc * 128 + 8 * ch);
+        }
+    };
+    tf32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    tu32x4 a0[4], b0[4];
+    int m0 = p_begin;
+    if (m0 < p_end) load_tile(m0, a0, b0);
+    while (m0 < p_end) {
+        __syncthreads();                                      // the previous tile's fragment reads (and, first time, the image reads) are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rg + 16 * i;
+            const bool ok = m < p_end;
+            const tu32x4 va = ok ? a0[i] : z4;
+            float v[8], dm[8], a1[8], gp[8];
+            unpack8(b0[i], v);
+            drop8(dr, key, (unsigned)m * 16u + ch, dm);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { float g, d; gelu_both_fast(v[q], g, d); a1[q] = g * dm[q]; gp[q] = d * dm[q]; }
+            *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = va;
+            *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? tpack8(a1) : z4;
+            *reinterpret_cast<tu32x4*>(tG + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? tpack8(gp) : z4;
+            if (cs_part) {
+                float w8[8];
+                unpack8(va, w8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) csum[q] += w8[q];
+            }
+        }
+        __syncthreads();
+        load_tile(m0 + 64, a0, b0);
+        // weight gradient: acc += dpre2^T a1 (transposed reads of both tiles)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tu32x4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(tA, 16 * ks, 64 * wr + 32 * a, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(tB, 16 * ks, 64 * wc + 32 * b, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+        }
+        // d pre1 of this wave's 32 rows x 64 channels: D = W2' . dpre2^T, the dpre2 rows as row-major fragments of the same LDS tile
+        {
+            const unsigned short* xrow = tA + (32 * wr + r) * TN_PITCH + 8 * h;
+            tf32x16 dn[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dn[u][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const tu32x4 xf = *reinterpret_cast<const tu32x4*>(xrow + 16 * ks);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) dn[u] = tmfma(wf[ks][u], xf, dn[u]);
+            }
+            const int m = m0 + 32 * wr + r;
+            const unsigned short* grow = tG + (32 * wr + r) * TN_PITCH + 8 * h;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int c = 32 * (2 * wc + u) + 16 * g;           // + 8 h (in grow / the store address)
+                    float gq[8], o[8];
+                    unpack8(*reinterpret_cast<const tu32x4*>(grow + c), gq);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = dn[u][8 * g + q] * gq[q];
+                    if (m < p_end) *reinterpret_cast<tu32x4*>(DX + (size_t)m * 128 + c + 8 * h) = tpack8(o);
+                }
+        }
+        m0 += 64;
+    }
+    if (cs_part) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cs_red[rg][8 * ch + q] = csum[q];
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += cs_red[g][tid];
+            cs_part[(size_t)blockIdx.z * pstride + tid] = t;
+        }
+    }
+    float* dst = part + (size_t)blockIdx.z * pstride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = 64 * wc + 32 * b + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(size_t)(64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[a][b][i];
+        }
+}
+// ---- the two kernels that consume d pre1, fused the same way: dWc += dpre1^T e (k_emm_tn, no activation) AND dE += dpre1 . Wc (k_emm128
+// with the old-Y epilogue): one pass over dpre1 instead of two.  The weight image is staged through the tile region before the first tile.
+__global__ void __launch_bounds__(256, 2) k_emm_bwd1(TRows rows, const tb16* __restrict__ dY, const tb16* __restrict__ Xin, tb16* __restrict__ DE,
+        const float* __restrict__ W, int ldw, const unsigned short* __restrict__ wimg, float* __restrict__ part, size_t pstride,
+        int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned short tAB[2 * 64 * TN_PITCH];     // [A tile | B tile]; first the 32-KiB weight image
+    unsigned short* tA = tAB;
+    unsigned short* tB = tAB + 64 * TN_PITCH;
+    const int R = nrows(rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
+    const int ch = tid & 15, rg = tid >> 4;
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    stage_wimage(tAB, wimg, W, ldw, false, 1, tid);
+    __syncthreads();
+    tu32x4 wf[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wf[ks][u] = reinterpret_cast<const tu32x4*>(tAB)[(ks * 4 + 2 * wc + u) * 64 + lane];
+    auto load_tile = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rg + 16 * i;
+            const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+            xa[i] = *reinterpret_cast<const tu32x4*>(dY + (size_t)mc * 128 + 8 * ch);
+            xb[i] = *reinterpret_cast<const tu32x4*>(Xin + (size_t)mc * 128 + 8 * ch);
+        }
+    };
+    tf32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    tu32x4 a0[4], b0[4];
+    int m0 = p_begin;
+    if (m0 < p_end) load_tile(m0, a0, b0);
+    while (m0 < p_end) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = m0 + rg + 16 * i < p_end;
+            *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? a0[i] : z4;
+            *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? b0[i] : z4;
+        }
+        __syncthreads();
+        load_tile(m0 + 64, a0, b0);
+        // the old dE of this lane's row (4 x 16 bytes: channel groups of its two channel blocks) goes out before the MFMAs
+        const int m = m0 + 32 * wr + r;
+        const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+        tu32x4 old[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) old[u][g] = *reinterpret_cast<const tu32x4*>(DE + (size_t)mc * 128 + 32 * (2 * wc + u) + 16 * g + 8 * h);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tu32x4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(tA, 16 * ks, 64 * wr + 32 * a, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(tB, 16 * ks, 64 * wc + 32 * b, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = tmfma(af[a], bf[b], acc[a][b]);
+        }
+        {
+            const unsigned short* xrow = tA + (32 * wr + r) * TN_PITCH + 8 * h;
+            tf32x16 dn[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dn[u][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const tu32x4 xf = *reinterpret_cast<const tu32x4*>(xrow + 16 * ks);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) dn[u] = tmfma(wf[ks][u], xf, dn[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float ov[8], o[8];
+                    unpack8(old[u][g], ov);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[q] = dn[u][8 * g + q] + ov[q];
+                    if (m < p_end) *reinterpret_cast<tu32x4*>(DE + (size_t)m * 128 + 32 * (2 * wc + u) + 16 * g + 8 * h) = tpack8(o);
+                }
+        }
+        m0 += 64;
+    }
+    float* dst = part + (size_t)blockIdx.z * pstride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = 64 * wc + 32 * b + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(size_t)(64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[a][b][i];
+        }
+}
+// dW[128][ldw_out] += dY^T X,  DE += dY . W       (W [128 out][ldw]: the Wc block of a first Linear)
+void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, const float* W, int ldw, float* dW, int ldw_out,
+                  const TScratch& sc, hipStream_t s) {
+    const size_t mk = 128 * 128;
+    long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
+    int splits = (rows.maxrows + 1023) / 1024;
+    const int want = 2 * rn_num_cus();
+    if (splits > want) splits = want;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    float* tmp = sc.p + (size_t)splits * mk;
+    hipLaunchKernelGGL(k_emm_bwd1, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, X, DE, W, ldw, wimg_lookup(W, ldw, false, 1), sc.p, mk, rps);
+    reduce_parts(sc.p, splits, mk, (int)mk, 128, dW, ldw_out, s, tmp);
+}
+// dW[128][ldw_out] += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask        (W [128 out][ldw] as nn.Linear stores it)
+void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
+                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
+    const size_t mk = 128 * 128;
+    long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
+    int splits = (rows.maxrows + 1023) / 1024;
+    const int want = 2 * rn_num_cus();                       // two resident workgroups per CU (72 KiB of LDS each)
+    if (splits > want) splits = want;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    const size_t pstride = mk + (dbias ? 128 : 0);
+    float* tmp = sc.p + (size_t)splits * pstride;
+    hipLaunchKernelGGL(k_emm_bwd2, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, PRE, DX, W, ldw, wimg_lookup(W, ldw, false, 1), sc.p, pstride,
+                       rps, dr, site, dbias ? sc.p + mk : (float*)nullptr);
+    reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw_out, s, tmp, (int)mk, dbias);
+}
+
 // ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
 // One wave per residue, lane = two adjacent channels.  The k validity flags are taken in ONE load + ballot (a per-slot `if (nbr >= 0)` in the
 // loop is a dependent load -> branch -> load chain per slot: 83 % of the wave cycles were waits), the row loads are unconditional and go
