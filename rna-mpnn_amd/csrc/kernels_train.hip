@@ -1678,6 +1678,145 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
     return true;
 }
 
+// ---- the forward of a depth-2 per-edge MLP in ONE kernel: pre1 = e . Wc^T + P[i] + Q[j] ; pre2 = drop(gelu(pre1)) . W2^T + b2 ;
+// [e_out = e + valid * drop(gelu(pre2))].  With the accumulators transposed (lane = row, a lane's 16 registers of a channel block = two runs
+// of 8 consecutive channels) the activated first-Linear output IS the B-operand fragment of the second Linear (k-step 2 cb + g <-> run g of
+// block cb): the hidden activation never leaves the registers, pre1 / pre2 are written once as the tape, and the e tile that was the
+// operand of the first Linear is still in registers when the edge update needs it.  Against the two-kernel form this saves the read of pre1
+// and (edge update) the second read of e.  Both weight images live in LDS (64 KiB, two workgroups per CU).
+struct Emm2Args {
+    TRows rows;
+    const tb16* X;                   // e [R][128]
+    const float* W1; int ldw1;       // Wc block of the first Linear ([128][ldw1], nn.Linear layout)
+    const float* W2; int ldw2; const float* bias2;
+    const unsigned short* wimg1; const unsigned short* wimg2;
+    tb16* pre1; tb16* pre2;
+    EFuse f;                         // P, Q, nbr, k, zero_row ; res_out (optional), site2
+    TDrop dr; unsigned site;         // dropout site of the hidden activation
+};
+template <bool RES>
+__global__ void __launch_bounds__(256, 2) k_emm_fwd2(Emm2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short img1[32 * 64 * 8], img2[32 * 64 * 8];
+    __shared__ __attribute__((aligned(16))) float lds_bias[128];
+    const int R = nrows(a.rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    stage_wimage(img1, a.wimg1, a.W1, a.ldw1, true, 1, tid);
+    stage_wimage(img2, a.wimg2, a.W2, a.ldw2, true, 1, tid);
+    if (tid < 128) lds_bias[tid] = a.bias2 ? a.bias2[tid] : 0.f;
+    __syncthreads();
+    const tu32x4* w1 = reinterpret_cast<const tu32x4*>(img1) + lane;
+    const tu32x4* w2 = reinterpret_cast<const tu32x4*>(img2) + lane;
+    const int ntiles = (R + 31) / 32;
+    const int tstride = gridDim.x * 4;
+    const unsigned key1 = drop_key(a.dr, a.site), key2 = drop_key(a.dr, a.f.site2);
+    tu32x4 raw[8];
+    int jn = -1;
+    auto load_raw = [&](int t) {
+        const int row = min(32 * t + r, R - 1);
+        const tb16* p = a.X + (size_t)row * 128 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) raw[ks] = *reinterpret_cast<const tu32x4*>(p + 16 * ks);
+        jn = a.f.nbr[row];
+    };
+    auto gemm = [&](const tu32x4* wimg, const tu32x4 (&xf)[8], tf32x16 (&acc)[4]) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+        tu32x4 wa[4], wb[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) wa[cb] = wimg[cb * 64];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) wb[cb] = wimg[((ks + 1) * 4 + cb) * 64];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wa[cb], xf[ks], acc[cb]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 8) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wa[cb] = wimg[((ks + 2) * 4 + cb) * 64];
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = tmfma(wb[cb], xf[ks + 1], acc[cb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int t = blockIdx.x * 4 + wave;
+    if (t < ntiles) load_raw(t);
+    for (; t < ntiles; t += tstride) {
+        const int row = 32 * t + r;
+        const bool rok = row < R;
+        const int rowc = rok ? row : R - 1;
+        const int j = jn;
+        tu32x4 xe[8];                                        // this row of e: operand of the first Linear, residual input of the edge update
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xe[ks] = rok ? raw[ks] : tu32x4{0u, 0u, 0u, 0u};
+        tu32x4 pp[8], qq[8];
+        {
+            const tb16* prow = a.f.P + (size_t)(rowc / a.f.k) * 128 + 8 * h;
+            const tb16* qrow = a.f.Q + (size_t)(j < 0 ? a.f.zero_row : (j > a.f.zero_row ? a.f.zero_row : j)) * 128 + 8 * h;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { pp[u] = *reinterpret_cast<const tu32x4*>(prow + 16 * u); qq[u] = *reinterpret_cast<const tu32x4*>(qrow + 16 * u); }
+        }
+        if (t + tstride < ntiles) load_raw(t + tstride);
+        tf32x16 acc[4];
+        gemm(w1, xe, acc);
+        // epilogue 1: pre1 = acc + P + Q (tape, bf16) ; hidden = drop(gelu(pre1 as stored)) -> operand fragments of the second Linear
+        tu32x4 xh[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = u >> 1, g = u & 1;
+            float v[8], pv[8], qv[8], dm[8];
+            unpack8(pp[u], pv); unpack8(qq[u], qv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = acc[cb][8 * g + q] + pv[q] + qv[q];
+            const tu32x4 y = tpack8(v);
+            if (rok) *reinterpret_cast<tu32x4*>(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h) = y;
+            unpack8(y, v);
+            drop8(a.dr, key1, (unsigned)row * 16u + 2 * u + h, dm);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * dm[q];
+            xh[u] = rok ? tpack8(v) : tu32x4{0u, 0u, 0u, 0u};
+        }
+        gemm(w2, xh, acc);
+        // epilogue 2: pre2 (tape) [+ edge update from the e row still in registers]
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int cb = u >> 1, g = u & 1, c = 16 * u + 8 * h;
+            float v[8];
+            const tf32x4 b0 = *reinterpret_cast<const tf32x4*>(lds_bias + c), b1 = *reinterpret_cast<const tf32x4*>(lds_bias + c + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = acc[cb][8 * g + q] + b0[q]; v[4 + q] = acc[cb][8 * g + 4 + q] + b1[q]; }
+            if (rok) *reinterpret_cast<tu32x4*>(a.pre2 + (size_t)row * 128 + c) = tpack8(v);
+            if constexpr (RES) {
+                float ei[8];
+                unpack8(xe[u], ei);
+                if (j >= 0) {
+                    float dm[8];
+                    drop8(a.dr, key2, (unsigned)row * 16u + 2 * u + h, dm);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ei[q] += gelu_fast(v[q]) * dm[q];
+                }
+                if (rok) *reinterpret_cast<tu32x4*>(a.f.res_out + (size_t)row * 128 + c) = tpack8(ei);
+            }
+        }
+    }
+}
+// pre1 = X . W1^T + P[row / k] + Q[nbr[row]] ; pre2 = drop(gelu(pre1), site) . W2^T + bias2 ; [res_out = X + valid drop(gelu(pre2), site2)]
+void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, const float* W2, int ldw2, const float* bias2, tb16* pre1,
+                 tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s) {
+    Emm2Args a;
+    a.rows = rows; a.X = X; a.W1 = W1; a.ldw1 = ldw1; a.W2 = W2; a.ldw2 = ldw2; a.bias2 = bias2; a.pre1 = pre1; a.pre2 = pre2; a.f = f;
+    a.dr = dr; a.site = site;
+    a.wimg1 = wimg_lookup(W1, ldw1, true, 1); a.wimg2 = wimg_lookup(W2, ldw2, true, 1);
+    int g = (rows.maxrows + 127) / 128;
+    const int cap = 2 * rn_num_cus();
+    const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
+    if (f.res_out) hipLaunchKernelGGL(k_emm_fwd2<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_emm_fwd2<false>, grid, dim3(256), 0, s, a);
+}
+
 // ---- TN with bf16 operands: dW[n][kk] += sum_m A[m][n] actB(B[m][kk]), M = K = 128.  Same scheme as k_mm_tn (64-row tiles row-major
 // in LDS, transposed fragment reads, row range split over blockIdx.z, ordered reduction of the partial tiles); the staging is a straight
 // 16-byte copy unless the activation prologue is on.
