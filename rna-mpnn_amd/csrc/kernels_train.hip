@@ -2193,7 +2193,7 @@ void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, co
                   const TScratch& sc, hipStream_t s) {
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
-    int splits = (rows.maxrows + 1023) / 1024;
+    int splits = (rows.maxrows + 511) / 512;                 // >= 8 tiles per workgroup; fills the chip from ~130 K rows on
     const int want = 2 * rn_num_cus();
     if (splits > want) splits = want;
     if (splits > cap) splits = (int)cap;
@@ -2208,7 +2208,7 @@ void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, 
                   const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
-    int splits = (rows.maxrows + 1023) / 1024;
+    int splits = (rows.maxrows + 511) / 512;                 // >= 8 tiles per workgroup; fills the chip from ~130 K rows on
     const int want = 2 * rn_num_cus();                       // two resident workgroups per CU (72 KiB of LDS each)
     if (splits > want) splits = want;
     if (splits > cap) splits = (int)cap;
