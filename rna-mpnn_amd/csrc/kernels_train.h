@@ -84,6 +84,10 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
 // dW[128][ldw] += A^T . actB(B), dbias += colsum(A)     (A, B bf16 [R][128])
 void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
                 unsigned site, float* dbias, hipStream_t s, int cols_keep = 128);      // cols_keep: live columns of B
+// the node-side GEMMs of a factored first Linear, each pair as one launch: P / Q tables, [dWa ; dWb] (+ db1), dh += dP Wa + dQ Wb
+void te_gemm_pq(const TRows& rows, const float* h, const float* w0, const float* b1, tb16* Pt, tb16* Qt, hipStream_t s);
+void tm_gemm_tn_pq(const TRows& rows, const float* dpq, const float* h, float* gw0, float* db1, const TScratch& sc, hipStream_t s);
+bool tm_gemm_nn_pq(const TRows& rows, const float* dpq, const float* w0, float* dh, hipStream_t s);
 // forward of a depth-2 per-edge MLP in one kernel (the hidden activation stays in registers; pre1 / pre2 written once as the tape)
 void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, const float* W2, int ldw2, const float* bias2, tb16* pre1,
                  tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s);

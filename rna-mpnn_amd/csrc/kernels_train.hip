@@ -118,14 +118,19 @@ void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, 
 // Every cross-workgroup sum of the backward goes through this (no float atomics): gradients are bit-reproducible.
 // Elements i >= split_at belong to a second, dense output (the bias gradient riding behind a weight-gradient tile): out2[i - split_at].
 __global__ void k_reduce_parts(const float* __restrict__ part, int nparts, size_t stride, int count, int cols,
-                               float* __restrict__ out, int ld_out, int split_at, float* __restrict__ out2, int cols_keep) {
+                               float* __restrict__ out, int ld_out, int split_at, float* __restrict__ out2, int cols_keep,
+                               int out2_keep, int wrap_rows, int wrap_shift) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float s = 0.f;
 #pragma unroll 8
     for (int p = 0; p < nparts; ++p) s += part[(size_t)p * stride + i];       // (loads batched by the unroll, additions in order)
-    if (i < split_at) { if (i % cols < cols_keep) out[(size_t)(i / cols) * ld_out + (i % cols)] += s; }      // (columns >= cols_keep: padding of the operand)
-    else out2[i - split_at] += s;
+    if (i < split_at) {
+        // (columns >= cols_keep: padding of the operand;  wrap_rows: output rows beyond it continue wrap_shift columns to the right -
+        //  the [Wa | Wb] blocks of a first Linear's weight gradient, produced as one 256-row product)
+        const int row = i / cols, c = i % cols;
+        if (c < cols_keep) out[(size_t)(wrap_rows ? row % wrap_rows : row) * ld_out + (wrap_rows ? (row / wrap_rows) * wrap_shift : 0) + c] += s;
+    } else if (i - split_at < out2_keep) out2[i - split_at] += s;
 }
 // first level of a two-level reduction: group g sums its contiguous run of partials (ascending) into tmp[g][count]
 __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size_t stride, int count, int per_group,
@@ -140,16 +145,18 @@ __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size
 }
 // (the association order is a function of nparts alone: bit-reproducible.  tmp: 16 * count floats behind the partials)
 static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s,
-                         float* tmp = nullptr, int split_at = -1, float* out2 = nullptr, int cols_keep = -1) {
+                         float* tmp = nullptr, int split_at = -1, float* out2 = nullptr, int cols_keep = -1, int out2_keep = -1,
+                         int wrap_rows = 0, int wrap_shift = 0) {
     if (split_at < 0) split_at = count;
     if (cols_keep < 0) cols_keep = cols;
+    if (out2_keep < 0) out2_keep = count;
     if (tmp && nparts > 96) {
         const int G = 16, per = (nparts + G - 1) / G;
         hipLaunchKernelGGL(k_reduce_groups, dim3((count + 255) / 256, G), dim3(256), 0, s, part, nparts, stride, count, per, tmp);
-        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out, split_at, out2, cols_keep);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, tmp, G, (size_t)count, count, cols, out, ld_out, split_at, out2, cols_keep, out2_keep, wrap_rows, wrap_shift);
         return;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out, split_at, out2, cols_keep);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((count + 255) / 256), dim3(256), 0, s, part, nparts, stride, count, cols, out, ld_out, split_at, out2, cols_keep, out2_keep, wrap_rows, wrap_shift);
 }
 
 // dW[m][k] += sum_p A[p][m] * B[p][k]   (32 x 32 tile per block; the row range is split over blockIdx.z, every split
@@ -1094,7 +1101,8 @@ static bool mm_ok(const void* X, int ldx, int K, const void* W, int ldw, bool b_
 }
 // LDS-tiled general GEMM (defined below, next to the transposed-read helper): false when the shape is not covered
 static bool launch_tmm(bool wt, const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
-                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s);
+                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s,
+                       const float* W_hi = nullptr, int k_split = 0);
 // Y = [beta Y] + actA(X) . W^T + bias            (W [N][K] row-major: nn.Linear.weight as it is stored)
 bool tm_gemm_nt(const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
                 int ldy, int beta, bool actA, const TDrop& dr, unsigned site, hipStream_t s) {
@@ -1165,7 +1173,7 @@ __device__ __forceinline__ tu32x4 tr_frag(const unsigned short* tile, int row0, 
 template <bool WT, int MT>
 __global__ void __launch_bounds__(256) k_tmm(TRows rows, const float* __restrict__ X, int ldx, int K, const float* __restrict__ W, int ldw,
         const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int beta, int actA, const float* __restrict__ epi_pre,
-        int ld_epi, TDrop dr, unsigned site) {
+        int ld_epi, TDrop dr, unsigned site, const float* __restrict__ W_hi, int k_split) {
     constexpr int BM = 64 * MT;
     __shared__ __attribute__((aligned(16))) unsigned short As[BM * TM_LD];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[WT ? 64 * TN_PITCH : 128 * TM_LD];
@@ -1199,7 +1207,8 @@ __global__ void __launch_bounds__(256) k_tmm(TRows rows, const float* __restrict
             for (int v = 0; v < 8; ++v) br[v] = *reinterpret_cast<const tf32x4*>(ws + 4 * v);
         } else {
             const int k = k0 + (tid >> 2), nb = col0 + (tid & 3) * 32;
-            const float* ws = W + (size_t)(k < K ? k : 0) * ldw + (nb + 31 < N ? nb : 0);
+            const int kc = k < K ? k : 0;                     // (NN: rows k >= k_split of W' come from a second block, W_hi)
+            const float* ws = (kc < k_split ? W + (size_t)kc * ldw : W_hi + (size_t)(kc - k_split) * ldw) + (nb + 31 < N ? nb : 0);
 #pragma unroll
             for (int v = 0; v < 8; ++v) br[v] = *reinterpret_cast<const tf32x4*>(ws + 4 * v);
         }
@@ -1292,18 +1301,20 @@ __global__ void __launch_bounds__(256) k_tmm(TRows rows, const float* __restrict
     }
 }
 static bool launch_tmm(bool wt, const TRows& rows, const float* X, int ldx, int K, const float* W, int ldw, const float* bias, int N, float* Y,
-                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s) {
+                       int ldy, int beta, bool actA, const float* epi_pre, int ld_epi, const TDrop& dr, unsigned site, hipStream_t s,
+                       const float* W_hi, int k_split) {
+    if (!W_hi) k_split = K;
     // 16-byte loads of 16 / 32 consecutive floats: K in whole half-tiles, aligned rows; NN: whole 32-column groups of W
     if (K % 32 || ldx % 4 || ldw % 4 || ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || (wt && N % 32) || K < 64) return false;
     const long long big = (long long)((rows.maxrows + 127) / 128) * ((N + 127) / 128);
     if (big >= 2 * rn_num_cus()) {
         dim3 grid((rows.maxrows + 127) / 128, (N + 127) / 128);
-        if (wt) hipLaunchKernelGGL((k_tmm<true, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
-        else hipLaunchKernelGGL((k_tmm<false, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+        if (wt) hipLaunchKernelGGL((k_tmm<true, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site, W_hi, k_split);
+        else hipLaunchKernelGGL((k_tmm<false, 2>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site, W_hi, k_split);
     } else {
         dim3 grid((rows.maxrows + 63) / 64, (N + 127) / 128);
-        if (wt) hipLaunchKernelGGL((k_tmm<true, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
-        else hipLaunchKernelGGL((k_tmm<false, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site);
+        if (wt) hipLaunchKernelGGL((k_tmm<true, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site, W_hi, k_split);
+        else hipLaunchKernelGGL((k_tmm<false, 1>), grid, dim3(256), 0, s, rows, X, ldx, K, W, ldw, bias, N, Y, ldy, beta, actA ? 1 : 0, epi_pre, ld_epi, dr, site, W_hi, k_split);
     }
     return true;
 }
@@ -1429,6 +1440,28 @@ void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* 
     reduce_parts(sc.p, splits, pstride, (int)pstride, K, dW, ldw, s, tmp, (int)mk, dbias);
 }
 
+// The node-side weight gradients of a factored first Linear in ONE product: [dWa ; dWb] = [dP | dQ]^T h (256 x 128), db1 = colsum(dP).
+// gw0 = the [128][384] gradient of the Linear's weight ([Wa | Wb | Wc] blocks): rows 0..127 of the product go to columns 0..127, rows
+// 128..255 to columns 128..255 of the same 128 output rows (the reduction's wrap).
+void tm_gemm_tn_pq(const TRows& rows, const float* dpq, const float* h, float* gw0, float* db1, const TScratch& sc, hipStream_t s) {
+    const int M = 256, K = 128;
+    const size_t mk = (size_t)M * K, pstride = mk + M;
+    long long cap = (long long)(sc.floats / pstride) - 16;
+    int splits = (rows.maxrows + 255) / 256;
+    const int want = rn_num_cus();                            // two 128-row output tiles per split
+    if (splits > want) splits = want;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    float* tmp = sc.p + (size_t)splits * pstride;
+    hipLaunchKernelGGL(k_mm_tn, dim3(2, 1, splits), dim3(256), 0, s, rows, dpq, 256, M, h, 128, K, sc.p, pstride, rps, 0, TDrop{0ull, 0u, 1.f}, 0u, sc.p + mk);
+    reduce_parts(sc.p, splits, pstride, (int)pstride, K, gw0, 3 * 128, s, tmp, (int)mk, db1, K, 128, 128, 128);
+}
+// dh += dP . Wa + dQ . Wb as one K = 256 product (w0 = [128][384] weight: Wa = columns 0..127, Wb = columns 128..255)
+bool tm_gemm_nn_pq(const TRows& rows, const float* dpq, const float* w0, float* dh, hipStream_t s) {
+    return launch_tmm(true, rows, dpq, 256, 256, w0, 3 * 128, nullptr, 128, dh, 128, 1, false, nullptr, 0, TDrop{0ull, 0u, 1.f}, 0u, s, w0 + 128, 128);
+}
+
 // ------------------------------------------------------------------------------------------
 // Adam with L2 weight decay, torch.optim.Adam semantics (foreach / fused CUDA form): bias-corrected moments,
 // denom = sqrt(v) / sqrt(1 - beta2^t) + eps.
@@ -1472,6 +1505,7 @@ struct EmmArgs {
     EFuse f; int has_pq, has_res;
     TDrop dr; unsigned site;
     const unsigned short* wimg;      // prebuilt fragment image of W (WImageCache) or null
+    int w_yoff; tb16* Y2; const unsigned short* wimg2;     // blockIdx.y = 1: second weight block (W + w_yoff, no bias) -> Y2   (P and Q tables in one launch)
     int kvalid;                      // columns of X / rows of W' beyond it do not exist (treated as zero weights)
 };
 // The [E][128] x [128][128] GEMM of the per-edge Linears with the output TRANSPOSED in the accumulators: D = W' . X^T, i.e. the weight
@@ -1491,8 +1525,10 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds_bias[128];
     const int R = nrows(a.rows);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    stage_wimage(img, a.wimg, a.W, a.ldw, B_ROWS, 1, tid, a.kvalid);
-    if (tid < 128) lds_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+    const bool second = blockIdx.y != 0;
+    tb16* __restrict__ Yp = second ? a.Y2 : a.Y;
+    stage_wimage(img, second ? a.wimg2 : a.wimg, second ? a.W + a.w_yoff : a.W, a.ldw, B_ROWS, 1, tid, a.kvalid);
+    if (tid < 128) lds_bias[tid] = (a.bias && !second) ? a.bias[tid] : 0.f;
     __syncthreads();
     const tu32x4* wimg = reinterpret_cast<const tu32x4*>(img) + lane;
     const int ntiles = (R + 31) / 32;
@@ -1541,7 +1577,7 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
                 for (int u = 0; u < 8; ++u) e0[u] = *reinterpret_cast<const tu32x4*>(a.epi_pre + ro + 16 * u);
             } else if constexpr (EP == 3) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) e0[u] = *reinterpret_cast<const tu32x4*>(a.Y + ro + 16 * u);
+                for (int u = 0; u < 8; ++u) e0[u] = *reinterpret_cast<const tu32x4*>(Yp + ro + 16 * u);
             }
             if constexpr (RES && EP != 1) {
 #pragma unroll
@@ -1639,7 +1675,7 @@ __global__ void __launch_bounds__(256, 2) k_emm128(EmmArgs a) {
                 }
             }
             if (rok) {
-                tb16* yrow = a.Y + (size_t)row * 128 + 64 * half + 8 * h;
+                tb16* yrow = Yp + (size_t)row * 128 + 64 * half + 8 * h;
 #pragma unroll
                 for (int uu = 0; uu < 4; ++uu) *reinterpret_cast<tu32x4*>(yrow + 16 * uu) = yo[uu];
                 if constexpr (RES) {
@@ -1660,6 +1696,7 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
     a.has_pq = a.f.P != nullptr; a.has_res = a.f.res_out != nullptr;
     a.kvalid = kvalid;
     a.wimg = wimg_lookup(W, ldw, w_rows, 1, kvalid);
+    a.w_yoff = 0; a.Y2 = nullptr; a.wimg2 = nullptr;
     int g = (rows.maxrows + 127) / 128;                      // 4 waves x one 32-row tile each
     const int cap = 2 * rn_num_cus();                        // two workgroups per CU (two waves per SIMD)
     const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
@@ -1676,6 +1713,19 @@ bool te_gemm(const TRows& rows, const void* X, bool x_bf16, int ldx, const float
     else return false;                                   // combination not instantiated: nothing was launched
 #undef EMM_GO
     return true;
+}
+
+// P = h Wa^T + b1 and Q = h Wb^T (bf16 tables [rows][128]) in one launch: w0 = [128][384] weight, Wa = columns 0..127, Wb = columns 128..255
+void te_gemm_pq(const TRows& rows, const float* h, const float* w0, const float* b1, tb16* Pt, tb16* Qt, hipStream_t s) {
+    EmmArgs a;
+    a.rows = rows; a.X = h; a.ldx = 128; a.W = w0; a.ldw = 3 * 128; a.bias = b1; a.Y = Pt; a.beta = 0; a.actA = 0; a.epi_pre = nullptr;
+    a.dr = TDrop{0ull, 0u, 1.f}; a.site = 0u;
+    a.f = EFuse{nullptr, nullptr, nullptr, 1, 0, nullptr, nullptr, 0u};
+    a.has_pq = 0; a.has_res = 0; a.kvalid = 128;
+    a.wimg = wimg_lookup(w0, 3 * 128, true, 1); a.w_yoff = 128; a.Y2 = Qt; a.wimg2 = wimg_lookup(w0 + 128, 3 * 128, true, 1);
+    int g = (rows.maxrows + 127) / 128;
+    const int cap = rn_num_cus();
+    hipLaunchKernelGGL((k_emm128<true, float, 0, false, false>), dim3(g > cap ? cap : (g < 1 ? 1 : g), 2), dim3(256), 0, s, a);
 }
 
 // ---- the forward of a depth-2 per-edge MLP in ONE kernel: pre1 = e . Wc^T + P[i] + Q[j] ; pre2 = drop(gelu(pre1)) . W2^T + b2 ;
