@@ -88,7 +88,8 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
 void te_gemm_pq(const TRows& rows, const float* h, const float* w0, const float* b1, tb16* Pt, tb16* Qt, hipStream_t s);
 void tm_gemm_tn_pq(const TRows& rows, const float* dpq, const float* h, float* gw0, float* db1, const TScratch& sc, hipStream_t s);
 bool tm_gemm_nn_pq(const TRows& rows, const float* dpq, const float* w0, float* dh, hipStream_t s);
-// forward of a depth-2 per-edge MLP in one kernel (the hidden activation stays in registers; pre1 / pre2 written once as the tape)
+// forward of a depth-2 per-edge MLP in one kernel (the hidden activation stays in registers; pre1 / pre2 written once as the tape;
+// pre1 = null: not kept)
 void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, const float* W2, int ldw2, const float* bias2, tb16* pre1,
                  tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s);
 // fused pair of a first Linear's backward: dW += dY^T X, DE += dY . W   (one pass over dY)

@@ -1744,7 +1744,7 @@ struct Emm2Args {
     EFuse f;                         // P, Q, nbr, k, zero_row ; res_out (optional), site2
     TDrop dr; unsigned site;         // dropout site of the hidden activation
 };
-template <bool RES>
+template <bool RES, bool TAPE1>       // TAPE1: pre1 is written (training tape); inference callers keep only pre2
 __global__ void __launch_bounds__(256, 2) k_emm_fwd2(Emm2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned short img1[32 * 64 * 8], img2[32 * 64 * 8];
     __shared__ __attribute__((aligned(16))) float lds_bias[128];
@@ -1822,7 +1822,7 @@ __global__ void __launch_bounds__(256, 2) k_emm_fwd2(Emm2Args a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = acc[cb][8 * g + q] + pv[q] + qv[q];
             const tu32x4 y = tpack8(v);
-            if (rok) *reinterpret_cast<tu32x4*>(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h) = y;
+            if (TAPE1 && rok) *reinterpret_cast<tu32x4*>(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h) = y;
             unpack8(y, v);
             drop8(a.dr, key1, (unsigned)row * 16u + 2 * u + h, dm);
 #pragma unroll
@@ -1863,8 +1863,9 @@ void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, co
     int g = (rows.maxrows + 127) / 128;
     const int cap = 2 * rn_num_cus();
     const dim3 grid(g > cap ? cap : (g < 1 ? 1 : g));
-    if (f.res_out) hipLaunchKernelGGL(k_emm_fwd2<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_emm_fwd2<false>, grid, dim3(256), 0, s, a);
+    if (f.res_out) hipLaunchKernelGGL((k_emm_fwd2<true, true>), grid, dim3(256), 0, s, a);
+    else if (pre1) hipLaunchKernelGGL((k_emm_fwd2<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_emm_fwd2<false, false>), grid, dim3(256), 0, s, a);
 }
 
 // ---- TN with bf16 operands: dW[n][kk] += sum_m A[m][n] actB(B[m][kk]), M = K = 128.  Same scheme as k_mm_tn (64-row tiles row-major

@@ -511,8 +511,14 @@ extern "C" int rdesign_forward(rdesign_handle h, const float* X, const float* ma
             EFuse f{Pt, Qt, w.nbr, K, (int)Nmax, nullptr, nullptr, 0u};
             tb16* cur = reinterpret_cast<tb16*>(w.E1);
             tb16* nxt = reinterpret_cast<tb16*>(w.E2);
-            r.bad |= !te_gemm(r.re(), w.hE, true, RD_H, w0, 3 * RD_H, true, nullptr, cur, 0, false, nullptr, &f, r.nodrop, 0u, s);
-            for (size_t i = 1; i < L.msg.size(); ++i) {
+            size_t first = 1;
+            if (L.msg.size() >= 2) {      // Linears 0 and 1 in one kernel: the hidden activation stays in registers, only the second pre-activation is written
+                te_mlp2_fwd(r.re(), reinterpret_cast<const tb16*>(w.hE), w0, 3 * RD_H, rdp(c, L.msg[1].w), RD_H, rdp(c, L.msg[1].b), nullptr, cur, f, r.nodrop, 0u, s);
+                first = 2;
+            } else {
+                r.bad |= !te_gemm(r.re(), w.hE, true, RD_H, w0, 3 * RD_H, true, nullptr, cur, 0, false, nullptr, &f, r.nodrop, 0u, s);
+            }
+            for (size_t i = first; i < L.msg.size(); ++i) {
                 r.bad |= !te_gemm(r.re(), cur, true, RD_H, rdp(c, L.msg[i].w), RD_H, true, rdp(c, L.msg[i].b), nxt, 0, true, nullptr, nullptr, r.nodrop, 0u, s);
                 tb16* t = cur; cur = nxt; nxt = t;
             }
