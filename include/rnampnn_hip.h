@@ -174,10 +174,15 @@ int rnampnn_sample_dev_seed(const float* logits, const float* mask, int32_t B, i
  *       oracle/rnampnn_oracle.py - so a step is reproducible and testable against autograd.  A call accepts
  *       B*T*k < 2^26 edge rows and B*T < 2^23 residues (32-bit pair indices); larger batches return RNAMPNN_ERR_BAD_ARG.  The
  *       activations the backward needs (the "tape") stay in `workspace`, which must be left untouched until
- *       rnampnn_train_backward has run.  logits (B,T,4) out.
+ *       rnampnn_train_backward has run.  logits (B,T,4) out; *tape_id receives the identity of this tape (ids grow
+ *       monotonically per handle, 0 is never issued).  A later forward / loss_and_grad into the SAME workspace destroys the
+ *       tape; forwards into different workspaces may be outstanding together (gradient accumulation over micro-batches,
+ *       `(loss1 + loss2).backward()`).
  *   rnampnn_train_backward - gradient of every parameter from dlogits (B,T,4) = d loss / d logits of ANY loss the
- *       caller built on the logits (torch autograd: torch.autograd.Function in rnampnn/model/rnampnn.py).
- *       accumulate = 0 overwrites `grad`, 1 adds to it.
+ *       caller built on the logits (torch autograd: torch.autograd.Function in rnampnn/model/rnampnn.py), for the tape
+ *       `tape_id` living in `workspace`; RNAMPNN_ERR_BAD_ARG when that tape has been overwritten or belongs to another
+ *       workspace / shape - never a silent backward through another forward's activations.  A tape may be walked more than once
+ *       (retain_graph).  accumulate = 0 overwrites `grad`, 1 adds to it.
  *   rnampnn_loss_and_grad  - both in one call around the reference loss: cross_entropy(softmax(logits)[valid], label)
  *       (softmax twice, rnampnn.py:151-154), mean over valid nucleotides.  labels (B,T) int32 class ids (ignored on
  *       padding); loss: device scalar; logits optional; grad overwritten.
@@ -194,12 +199,20 @@ int     rnampnn_weight_offset(rnampnn_handle h, int32_t i, int64_t* offset);
                                     /* tensor in HBM (the tape), node-sized tensors and all reductions stay f32                */
 int     rnampnn_train_forward(rnampnn_handle h, const float* coords, const float* mask, int32_t B, int32_t T,
                               int32_t T_norm, float dropout, uint64_t seed, int32_t flags, float* logits,
-                              void* workspace, size_t workspace_bytes, void* stream);
-int     rnampnn_train_backward(rnampnn_handle h, const float* dlogits, int32_t B, int32_t T, int32_t accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream, int64_t* tape_id);
+int     rnampnn_train_backward(rnampnn_handle h, int64_t tape_id, const float* dlogits, int32_t B, int32_t T, int32_t accumulate,
                                float* grad, void* workspace, size_t workspace_bytes, void* stream);
 int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float* mask, const int32_t* labels,
                               int32_t B, int32_t T, int32_t T_norm, float dropout, uint64_t seed, int32_t flags,
                               float* loss, float* logits, float* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* Overlap of the data-parallel gradient all-reduce with the backward (Lightning DDP's bucketed overlap in the
+ * reference, rnampnn/utils/train.py:106-117).  The flat gradient is final in three contiguous chunks, in this order:
+ * 0 = [post_fusion .. readout], 1 = ResMPNN layers L/2 .. L-1, 2 = the rest (end of the backward).  rnampnn_grad_chunks reports
+ * their float ranges (begin[3], end[3]); rnampnn_set_grad_events registers two hipEvent_t (or null) that every later backward
+ * records on its stream when chunk 0 / chunk 1 is final: the caller's side stream waits on them and all-reduces that range
+ * while the rest of the backward runs. */
+int     rnampnn_grad_chunks(rnampnn_handle h, int64_t* begin, int64_t* end);
+int     rnampnn_set_grad_events(rnampnn_handle h, void* ev0, void* ev1);
 /* Optimiser support (F2).  rnampnn_use_weight_arena: the caller's flat f32 buffer (rnampnn_grad_numel() elements, tensor i
  * at rnampnn_weight_offset(i)) becomes the library's weight storage - the nn.Parameters of the Python module are views
  * of it, so an optimiser step needs no re-upload.  rnampnn_adam_step: torch.optim.Adam (betas, eps, L2 weight decay:

@@ -95,13 +95,14 @@ struct rnampnn_ctx {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     long long prof_n = 0;
-    // tape of the last rnampnn_train_forward (the activations themselves live in the caller's workspace)
-    bool tape_valid = false;
-    int tape_B = 0, tape_T = 0, tape_tnorm = 0;
-    float tape_p = 0.f;
-    uint64_t tape_seed = 0;
-    const void* tape_ws = nullptr;
-    bool tape_mixed = false;
+    // tapes of rnampnn_train_forward calls whose backward may still come (the activations themselves live in the caller's
+    // workspaces): one record per workspace, identified by a monotonically increasing id that rnampnn_train_backward must present
+    struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; };
+    std::vector<Tape> tapes;
+    int64_t tape_counter = 0;
+    // optional: events the backward records on its stream once a chunk of the flat gradient is final (rnampnn_grad_chunks),
+    // so that the caller's all-reduce of that chunk can run on a side stream under the rest of the backward
+    hipEvent_t grad_ev[2] = {nullptr, nullptr};
     WImageCache* wimg = nullptr;   // prebuilt weight-fragment images of the bf16-mixed trainer (kernels_train.h)
     bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
     // fork / join inside one forward: independent branches of the node stack run on auxiliary streams beside the

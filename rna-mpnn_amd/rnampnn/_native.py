@@ -69,10 +69,12 @@ SYMBOLS = {
     "rnampnn_train_workspace_bytes": (_SZ, [_VP, _I32, _I32]),
     "rnampnn_grad_numel": (_I64, [_VP]),
     "rnampnn_weight_offset": (C.c_int, [_VP, _I32, C.POINTER(_I64)]),
-    "rnampnn_train_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _SZ, _VP]),
+    "rnampnn_train_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _SZ, _VP, C.POINTER(_I64)]),
+    "rnampnn_grad_chunks": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    "rnampnn_set_grad_events": (C.c_int, [_VP, _VP, _VP]),
     "rnampnn_use_weight_arena": (C.c_int, [_VP, _VP, _VP]),
     "rnampnn_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F, _F, _F, _F, _F, _I32, _VP]),
-    "rnampnn_train_backward": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _SZ, _VP]),
+    "rnampnn_train_backward": (C.c_int, [_VP, _I64, _VP, _I32, _I32, _I32, _VP, _VP, _SZ, _VP]),
     "rnampnn_loss_and_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_profile_enable": (C.c_int, [_VP, _I32]),
     "rnampnn_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),

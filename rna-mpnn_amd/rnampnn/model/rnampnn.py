@@ -104,41 +104,65 @@ class RNAMPNN(NativeModule):
         self._drop_calls = getattr(self, "_drop_calls", 0) + 1
         return (getattr(self, "_drop_base", 0) << 32) + self._drop_calls
 
-    def _train_ws(self, B: int, T: int, device):
-        need = int(_native.lib().rnampnn_train_workspace_bytes(self._handle.ptr, B, T))
-        if getattr(self, "_tws", None) is None or self._tws.numel() < need + 256 or self._tws.device != device:
-            self._tws = None
-            self._tws = torch.empty(need + 256, dtype=torch.uint8, device=device)
-        base = self._tws.data_ptr()
+    # Tape workspaces.  A taped forward leaves its activations in a workspace until the matching backward has run, so every
+    # forward whose backward may still come OWNS one (a ``_TapeLease`` held by its autograd node): two micro-batches before
+    # one ``backward()`` get two workspaces, and the lease of a graph that is dropped without a backward is returned when the
+    # graph is freed.  Unleased slots double as the scratch of the calls that finish inside one native call
+    # (``loss_and_grad``, ``forward`` under ``no_grad``).
+    def _tape_slot(self, B: int, T: int, device, lease: bool):
+        """-> (slot, lease or None).  The slot never references its lease (the lease must die with the autograd node)."""
+        need = int(_native.lib().rnampnn_train_workspace_bytes(self._handle.ptr, B, T)) + 256
+        pool = self.__dict__.setdefault("_tape_pool", [])
+        pick = None
+        for slot in pool:
+            if not slot["busy"] and slot["ws"].device == device and (pick is None or pick["ws"].numel() < need <= slot["ws"].numel()):
+                pick = slot
+        if pick is None:
+            pick = {"ws": torch.empty(need, dtype=torch.uint8, device=device), "busy": False}
+            pool.append(pick)
+        elif pick["ws"].numel() < need:
+            pick["ws"] = None
+            pick["ws"] = torch.empty(need, dtype=torch.uint8, device=device)
+        return pick, (_TapeLease(pick) if lease else None)
+
+    @staticmethod
+    def _ws_ptr(slot):
+        base = slot["ws"].data_ptr()
         aligned = (base + 255) // 256 * 256
-        return C.c_void_p(aligned), C.c_size_t(self._tws.numel() - (aligned - base))
+        return C.c_void_p(aligned), C.c_size_t(slot["ws"].numel() - (aligned - base))
 
     def _train_flags(self) -> int:
         if self.train_precision not in ("f32", "bf16"):
             raise ValueError("train_precision must be 'f32' or 'bf16'")
         return _native.TRAIN_BF16_MIXED if self.train_precision == "bf16" else _native.TRAIN_F32
 
-    def _train_forward_native(self, coords, mask, T_norm: int, dropout: float, seed: int) -> torch.Tensor:
+    def _train_forward_native(self, coords, mask, T_norm: int, dropout: float, seed: int, lease: bool = False):
+        """-> logits, or (logits, lease) when the caller will run a backward on this tape."""
         device = self._ensure(for_mixed_training=self.train_precision == "bf16")
         B, T = int(coords.shape[0]), int(coords.shape[1])
         c, m = _prep(coords, device), _prep(mask, device)
         logits = torch.empty(B, T, 4, dtype=torch.float32, device=device)
+        slot, ls = self._tape_slot(B, T, device, lease)
+        tape = C.c_int64(0)
         with torch.cuda.device(device):
-            ws, ws_bytes = self._train_ws(B, T, device)
+            ws, ws_bytes = self._ws_ptr(slot)
             _native.check(_native.lib().rnampnn_train_forward(self._handle.ptr, _ptr(c), _ptr(m), B, T, int(T_norm), float(dropout),
                                                               C.c_uint64(int(seed) & (2 ** 64 - 1)), self._train_flags(),
-                                                              _ptr(logits), ws, ws_bytes, _stream(device)))
-        return logits
+                                                              _ptr(logits), ws, ws_bytes, _stream(device), C.byref(tape)))
+        if not lease:
+            return logits
+        ls.tape_id = int(tape.value)
+        return logits, ls
 
-    def _train_backward_native(self, dlogits: torch.Tensor) -> None:
+    def _train_backward_native(self, dlogits: torch.Tensor, lease: "_TapeLease") -> None:
         device = self._device()
         B, T = int(dlogits.shape[0]), int(dlogits.shape[1])
         fresh = self._bind_flat_grad(device)
         d = _prep(dlogits, device)
         with torch.cuda.device(device):
-            ws, ws_bytes = self._train_ws(B, T, device)
-            _native.check(_native.lib().rnampnn_train_backward(self._handle.ptr, _ptr(d), B, T, 0 if fresh else 1,
-                                                               _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
+            ws, ws_bytes = self._ws_ptr(lease.slot)
+            _native.check(_native.lib().rnampnn_train_backward(self._handle.ptr, C.c_int64(lease.tape_id), _ptr(d), B, T,
+                                                               0 if fresh else 1, _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
 
     def _forward_train(self, coords, mask, T_norm: int = 0, dropout: Optional[float] = None, seed: Optional[int] = None):
         """The reference's ``self(coords, mask)`` inside ``training_step`` (rnampnn.py:199): logits carrying an autograd
@@ -270,7 +294,7 @@ class RNAMPNN(NativeModule):
         p = float((self._hp["dropout"] if self.training else 0.0) if dropout is None else dropout)
         sd = self._next_seed() if seed is None else int(seed)
         with torch.cuda.device(device):
-            ws, ws_bytes = self._train_ws(B, T, device)
+            ws, ws_bytes = self._ws_ptr(self._tape_slot(B, T, device, lease=False)[0])
             _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm), p,
                                                     C.c_uint64(sd & (2 ** 64 - 1)), self._train_flags(), _ptr(loss), _ptr(logits),
                                                     _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
@@ -311,13 +335,65 @@ class RNAMPNN(NativeModule):
         valid = mask.bool()
         return self.mix_loss(probs[valid], sequences[valid])
 
-    def allreduce_gradients(self) -> None:
-        """Average ``flat_grad`` over the ranks of the default process group (RCCL on the GPUs): the one
-        collective of data-parallel training (Lightning DDP in the reference, utils/train.py:106-117)."""
+    def grad_chunks(self):
+        """[(begin, end)] float ranges of ``flat_grad`` in the order the HIP backward finishes them (``rnampnn_grad_chunks``):
+        the tail of the model (post-fusion .. read-out) first, then ResMPNN layers L/2 .. L-1, then the rest."""
+        self._ensure(for_mixed_training=True)
+        b, e = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+        _native.check(_native.lib().rnampnn_grad_chunks(self._handle.ptr, b, e))
+        return [(int(b[i]), int(e[i])) for i in range(3)]
+
+    def enable_allreduce_overlap(self, enable: bool = True) -> None:
+        """Data-parallel runs: let ``allreduce_gradients`` start on a side stream while the backward is still running.  The
+        backward records an event when the first / second chunk of ``flat_grad`` is final; the side stream waits on it and
+        all-reduces that range under the remaining backward kernels (Lightning DDP's bucket overlap in the reference,
+        utils/train.py:106-117).  Only the last chunk's all-reduce is exposed."""
+        device = self._ensure(for_mixed_training=True)
+        if not enable:
+            _native.check(_native.lib().rnampnn_set_grad_events(self._handle.ptr, None, None))
+            self._ar = None
+            return
+        evs = [torch.cuda.Event(), torch.cuda.Event()]
+        with torch.cuda.device(device):
+            for ev in evs:
+                ev.record(torch.cuda.current_stream(device))     # (creates the underlying hipEvent_t)
+        _native.check(_native.lib().rnampnn_set_grad_events(self._handle.ptr, C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)))
+        self._ar = dict(stream=torch.cuda.Stream(device), events=evs, chunks=self.grad_chunks())
+
+    def allreduce_gradients(self, timing=None) -> None:
+        """Average ``flat_grad`` over the ranks of the default process group (RCCL on the GPUs): the one exchange of
+        data-parallel training (Lightning DDP in the reference, utils/train.py:106-117).  After
+        ``enable_allreduce_overlap()`` the buffer goes out in the three chunks of ``grad_chunks`` on a side stream, each as
+        soon as the backward has finished it; the caller's stream then waits for the side stream.  ``timing``: an optional
+        pair of ``torch.cuda.Event(enable_timing=True)`` recorded on the caller's stream around that wait - their distance is
+        the all-reduce time NOT hidden under the backward."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        world = dist.get_world_size()
+        ar = getattr(self, "_ar", None)
+        if ar is None or self.flat_grad.device.type != "cuda":
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.div_(dist.get_world_size())
+            self.flat_grad.div_(world)
+            return
+        device = self.flat_grad.device
+        main, side = torch.cuda.current_stream(device), ar["stream"]
+        inv = 1.0 / world
+        with torch.cuda.stream(side):
+            for i, (b, e) in enumerate(ar["chunks"]):
+                if i < 2:
+                    side.wait_event(ar["events"][i])
+                else:
+                    side.wait_stream(main)                   # the last chunk is final when the backward ends
+                if e > b:
+                    part = self.flat_grad[b:e]
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+                    part.mul_(inv)
+        if timing is not None:
+            timing[0].record(main)
+        main.wait_stream(side)
+        if timing is not None:
+            timing[1].record(main)
 
     @staticmethod
     def mix_loss(valid_probs, valid_sequences):
@@ -357,18 +433,79 @@ class RNAMPNN(NativeModule):
 
 class FlatAdam(torch.optim.Optimizer):
     """``torch.optim.Adam`` (default betas / eps, L2 weight decay) for an ``RNAMPNN`` whose parameters and gradients are
-    views of two flat buffers: one ``rnampnn_adam_step`` launch per step.  One parameter group, so ``StepLR`` and friends
-    work on it unchanged; ``zero_grad`` zeroes the flat gradient buffer in place (the views stay bound)."""
+    views of two flat buffers: one ``rnampnn_adam_step`` launch per step.  Exactly one parameter group (``add_param_group``
+    raises), so ``StepLR`` and friends work on it unchanged; ``zero_grad`` zeroes the flat gradient buffer in place (the
+    views stay bound).  ``state_dict`` / ``load_state_dict`` carry the step count and both moment buffers (key
+    ``"flat_adam"``), so a checkpoint / resume continues the same Adam trajectory; a ``torch.optim.Adam`` state dict of the
+    same model (per-parameter ``exp_avg`` / ``exp_avg_sq`` / ``step``) loads too."""
 
     def __init__(self, model: "RNAMPNN", lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self._sealed = False
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._sealed = True
         self.model = model
         self.t = 0
         self.exp_avg = self.exp_avg_sq = None
 
+    def add_param_group(self, param_group) -> None:
+        if getattr(self, "_sealed", False):
+            raise ValueError("FlatAdam updates the module's ONE flat parameter buffer with one lr / weight decay: a second "
+                             "parameter group would be silently ignored - use torch.optim.Adam for per-group settings")
+        super().add_param_group(param_group)
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         if getattr(self.model, "flat_grad", None) is not None:
             self.model.flat_grad.zero_()
+
+    def _moments(self, device):
+        if self.exp_avg is None or self.exp_avg.device != device or self.exp_avg.numel() != self.model._flat_param.numel():
+            old = (self.exp_avg, self.exp_avg_sq)
+            self.exp_avg = torch.zeros_like(self.model._flat_param)
+            self.exp_avg_sq = torch.zeros_like(self.model._flat_param)
+            if old[0] is not None and old[0].numel() == self.exp_avg.numel():      # the module moved to another device
+                self.exp_avg.copy_(old[0]); self.exp_avg_sq.copy_(old[1])
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_adam"] = {"t": int(self.t),
+                           "exp_avg": None if self.exp_avg is None else self.exp_avg.detach().clone(),
+                           "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.detach().clone()}
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict) -> None:
+        sd = dict(state_dict)
+        flat = sd.pop("flat_adam", None)
+        per_param = sd.get("state") or {}
+        sd["state"] = {}                                        # torch's loader casts / maps per-parameter state: ours is flat
+        super().load_state_dict(sd)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam: a state dict with one parameter group is required")
+        m = self.model
+        device = m._ensure(for_mixed_training=True)
+        if flat is not None:
+            self.t = int(flat["t"])
+            if flat["exp_avg"] is None:
+                self.exp_avg = self.exp_avg_sq = None
+            else:
+                if flat["exp_avg"].numel() != m._flat_param.numel():
+                    raise ValueError("FlatAdam: moment buffers of another model")
+                self.exp_avg = flat["exp_avg"].to(device=device, dtype=torch.float32).clone()
+                self.exp_avg_sq = flat["exp_avg_sq"].to(device=device, dtype=torch.float32).clone()
+        elif per_param:                                         # a torch.optim.Adam state dict: pack the per-parameter moments
+            if len(per_param) != len(m._param_slices):
+                raise ValueError("FlatAdam: per-parameter optimiser state does not cover every parameter of the model")
+            self.exp_avg = torch.zeros_like(m._flat_param)
+            self.exp_avg_sq = torch.zeros_like(m._flat_param)
+            steps = set()
+            for i, (_, off, numel) in enumerate(m._param_slices):       # parameter order = Optimizer's index order
+                st = per_param[i]
+                self.exp_avg[off: off + numel].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off: off + numel].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            if len(steps) != 1:
+                raise ValueError("FlatAdam: parameters with different step counts cannot share one bias correction")
+            self.t = steps.pop()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -377,10 +514,10 @@ class FlatAdam(torch.optim.Optimizer):
         device = m._ensure(for_mixed_training=True)              # parameters aliased to the flat buffer; no finalize here
         if getattr(m, "flat_grad", None) is None:
             return loss                                          # no backward has run yet
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FlatAdam supports exactly one parameter group")
         m._bind_flat_grad(device)
-        if self.exp_avg is None or self.exp_avg.device != device:
-            self.exp_avg = torch.zeros_like(m._flat_param)
-            self.exp_avg_sq = torch.zeros_like(m._flat_param)
+        self._moments(device)
         g = self.param_groups[0]
         self.t += 1
         with torch.cuda.device(device):
@@ -392,20 +529,35 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
 
+class _TapeLease:
+    """Ownership of one tape workspace by the autograd node of one taped forward: returned to the pool when the node (the
+    graph) is freed - after its backward, or without one."""
+
+    def __init__(self, slot):
+        self.slot, self.tape_id = slot, 0
+        slot["busy"] = True
+
+    def __del__(self):
+        self.slot["busy"] = False
+
+
 class _TrainForward(torch.autograd.Function):
     """Autograd node of the taped HIP forward.  The parameters are inputs only so that autograd schedules ``backward``;
     their gradients are written by the HIP backward straight into the module's flat buffer (``p.grad`` are views of it,
-    accumulated across backward calls until the gradients are reset, as torch does), so ``None`` is returned for them."""
+    accumulated across backward calls until the gradients are reset, as torch does), so ``None`` is returned for them.
+    The node holds the lease of ITS tape (workspace + tape id): several forwards before one backward each walk their own
+    activations and dropout masks, and the library refuses a tape that no longer exists."""
 
     @staticmethod
     def forward(ctx, model, coords, mask, T_norm, dropout, seed, *params):
         ctx.model = model
         ctx.n_params = len(params)
-        return model._train_forward_native(coords, mask, T_norm, dropout, seed)
+        logits, ctx.lease = model._train_forward_native(coords, mask, T_norm, dropout, seed, lease=True)
+        return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.model._train_backward_native(dlogits)
+        ctx.model._train_backward_native(dlogits, ctx.lease)
         return (None,) * (6 + ctx.n_params)
 
 
@@ -462,6 +614,14 @@ class CapturedSampler:
                 self._step()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
+        self._capture()
+
+    def _capture(self):
+        # the graph bakes in raw pointers: the private workspace, the static io tensors and the module's flat parameter
+        # buffer (biases and GraphNorm scale / shift are read from it directly).  That buffer is re-allocated whenever a
+        # parameter stops aliasing it (module.to(), load_state_dict(assign=True), p.data = ...): its address is recorded
+        # here and checked before every replay.
+        self._arena_ptr = self.model._flat_param.data_ptr()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.logits, self.samples = self._step()
@@ -478,9 +638,15 @@ class CapturedSampler:
     @torch.no_grad()
     def __call__(self, coords: torch.Tensor, mask: torch.Tensor, seed: int = 0):
         """-> (logits (B,T,4), samples int8 (n_samples,B,T)) - static tensors, overwritten by the next call.
-        Weights changed since the capture (optimizer step, load_state_dict) are re-uploaded first: the graph reads the
-        library's weight arena, whose address does not change."""
-        self.model._ensure()
+        Weights changed IN PLACE since the capture (optimizer step, load_state_dict) are picked up: ``_ensure`` rebuilds the
+        kernel-side layouts in the derived arena the graph already points at.  If the flat parameter buffer itself moved,
+        the graph is captured again (its old kernels would read freed memory)."""
+        device = self.model._ensure()
+        if self.model._flat_param.data_ptr() != self._arena_ptr or self.coords.device != device:
+            if self.coords.device != device:
+                raise RuntimeError("CapturedSampler: the model moved to another device after the capture; build a new sampler")
+            torch.cuda.synchronize(device)
+            self._capture()
         self.coords.copy_(coords, non_blocking=True)
         self.mask.copy_(mask, non_blocking=True)
         self.seed.fill_(int(seed) & (2 ** 63 - 1))

@@ -195,3 +195,78 @@ class PackedLoader:
                 dc.record_stream(torch.cuda.current_stream(self.device))
             yield dp, dc, max_len, b
         th.join()
+
+
+def pad_batch(items: Sequence, pin: bool = True):
+    """The reference collate's layout (``featurize``, utils/data.py:110-142) for (coords (L,7,3), labels (L,)) pairs, built in
+    pinned host memory: (labels (B,T) int32, coords (B,T,7,3) f32, mask (B,T) f32, lengths (B,) list).  Labels are class ids
+    (the one-hot of the reference is an argmax away and 4x the bytes)."""
+    lens = [int(c.shape[0]) for c, _ in items]
+    B, T = len(items), max(lens)
+    pin = pin and torch.cuda.is_available()
+    coords = torch.zeros((B, T, 7, 3), dtype=torch.float32, pin_memory=pin)
+    mask = torch.zeros((B, T), dtype=torch.float32, pin_memory=pin)
+    labels = torch.zeros((B, T), dtype=torch.int32, pin_memory=pin)
+    for i, (c, y) in enumerate(items):
+        n = lens[i]
+        coords[i, :n] = torch.as_tensor(c, dtype=torch.float32)
+        labels[i, :n] = torch.as_tensor(y).to(torch.int32)
+        mask[i, :n] = 1.0
+    return labels, coords, mask, lens
+
+
+class PaddedLoader:
+    """``PackedLoader``'s sibling for the TRAINING entry points, which take the collate's padded layout: a background thread
+    builds the next batches with ``pad_batch`` in pinned memory and issues their host-to-device copies on a side stream;
+    ``__iter__`` yields (labels, coords, mask, lengths, indices) with the three tensors already on the device and the
+    consumer's stream waiting on the copy's event only.  ``lengths`` stays on the host: the trainer counts nucleotides without
+    a device round trip.  ``items``: (id, coords, labels) tuples (``load_rna_dir``) or (coords, labels) pairs."""
+
+    def __init__(self, items, batches: Sequence[Sequence[int]], device=None, prefetch: int = 2):
+        self.items, self.batches, self.prefetch = items, [list(b) for b in batches], max(1, int(prefetch))
+        self.device = torch.device(device) if device is not None else None
+
+    def _pair(self, i):
+        it = self.items[i]
+        return (it[1], it[2]) if len(it) == 3 else (it[0], it[1])
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        q: "_queue.Queue" = _queue.Queue(maxsize=self.prefetch)
+        use_gpu = self.device is not None and self.device.type == "cuda"
+        side = torch.cuda.Stream(self.device) if use_gpu else None
+
+        def worker():
+            try:
+                for b in self.batches:
+                    y, c, m, lens = pad_batch([self._pair(i) for i in b], pin=use_gpu)
+                    if use_gpu:
+                        with torch.cuda.stream(side):
+                            dy, dc, dm = (t.to(self.device, non_blocking=True) for t in (y, c, m))
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                        q.put((dy, dc, dm, lens, b, ev, (y, c, m)))        # keep the pinned sources alive until consumed
+                    else:
+                        q.put((y, c, m, lens, b, None, None))
+                q.put(None)
+            except BaseException as exc:
+                q.put(exc)
+
+        th = _threading.Thread(target=worker, daemon=True)
+        th.start()
+        while True:
+            got = q.get()
+            if got is None:
+                break
+            if isinstance(got, BaseException):
+                raise got
+            dy, dc, dm, lens, b, ev, _keep = got
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for t in (dy, dc, dm):
+                    t.record_stream(cur)
+            yield dy, dc, dm, lens, b
+        th.join()

@@ -67,3 +67,19 @@ def reduce_recovery(correct: torch.Tensor, valid: torch.Tensor) -> Tuple[float, 
     micro = float(stats[0] / stats[1].clamp(min=1))
     macro = float(stats[2] / stats[3].clamp(min=1))
     return micro, macro
+
+
+def allreduce_mean_chunks(flat: torch.Tensor, chunks: Sequence[Tuple[int, int]]) -> None:
+    """Average ``flat`` over the ranks in the given [begin, end) ranges, one collective per range (the host-side form of
+    ``RNAMPNN.allreduce_gradients`` with overlap enabled, without the stream plumbing).  The ranges must tile the buffer."""
+    covered = sorted(chunks)
+    if covered[0][0] != 0 or covered[-1][1] != flat.numel() or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+        raise ValueError(f"gradient chunks {list(chunks)} do not tile a buffer of {flat.numel()} elements")
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    inv = 1.0 / dist.get_world_size()
+    for b, e in chunks:
+        if e > b:
+            part = flat[b:e]
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            part.mul_(inv)

@@ -30,7 +30,12 @@ def test_bench_spawns_its_own_ranks_and_reports_n_gpus():
     assert out["config"]["nucleotides_per_step_per_gpu"] == 32 * 200          # whole RNAs, balanced
     assert out["scaling"] == "strong" and out["unit"] == "nucleotides/s" and out["higher_is_better"] is True
     assert out["vs_baseline"] is None and "cpu_baseline" not in out
-    assert out["train"]["allreduce_bytes"] == 3536900 * 4 and out["train"]["steps"] == 3
+    assert out["train"]["allreduce_bytes"] == 3536900 * 4 and out["train"]["steps"] == 5
+    assert "allreduce_exposed_ms" in out["train"] and sum(out["train"]["allreduce_chunks_floats"]) == 3536900
+    # the weak-scaling leg: the N = 1 workload (C2, 256 RNAs) on every rank, comparable with the N = 1 line
+    w = out["weak_c2"]
+    assert w["scaling"] == "weak" and w["workload"].startswith("C2: batch=256 RNAs") and w["steps"] == 2
+    assert w["nucleotides_per_step_all_ranks"] > 2 * 256 * 100 and w["value"] > 0 and w["unit"] == "nucleotides/s"
     for key in ("metric", "value", "ms_per_step", "dtype", "data", "roofline"):
         assert key in out
 

@@ -109,3 +109,36 @@ def test_oracle_train_mode_is_eval_mode_at_p0_and_unbiased():
     d2, _ = O.forward(c, m, sd, cfg, dropout=0.4, seed=2)
     assert not torch.equal(d1, d2) and torch.isfinite(d1).all()
     assert (d1[m == 0] == 0).all()                                                      # padded rows stay zero in train mode
+
+
+def test_epoch_plan_pad_batch_and_config3_length_fixture():
+    """Round 3: the trainer's epoch plan is a pure function of (lengths, world, seed) whose per-rank columns are disjoint, equal
+    in step count and length-matched per step; pad_batch reproduces the collate layout; the committed config-3 length list is
+    the reference's data/train_data.csv (2,083 ids, 1,205,038 nt, 1 ... 4,417 nt, median 76)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import REPO
+    from rnampnn.utils.data import pad_batch
+    from rnampnn.utils.train import plan_epoch
+    lens = np.load(os.path.join(REPO, "tests", "data", "c3_train_lengths.npy"), allow_pickle=False)
+    assert lens.dtype == np.int32 and len(lens) == 2083 and int(lens.sum()) == 1205038
+    assert int(lens.min()) == 1 and int(lens.max()) == 4417 and int(np.median(lens)) == 76
+    cols = [plan_epoch(lens, r, 4, 512, 32768, seed=3) for r in range(4)]
+    steps = {len(c[0]) for c in cols}
+    assert len(steps) == 1
+    seen = [i for c in cols for b in c[0] for i in b]
+    assert len(seen) == len(set(seen)) and len(seen) >= 0.95 * len(lens)          # at most the unfilled last round is dropped
+    assert all(cols[0][1] == c[1] for c in cols)                                  # every rank derives the same global lengths
+    for s in range(steps.pop()):
+        rows = [len(c[0][s]) * max(int(lens[i]) for i in c[0][s]) for c in cols]
+        assert max(rows) <= 32768 or all(len(c[0][s]) == 1 for c in cols if len(c[0][s]) * max(int(lens[i]) for i in c[0][s]) > 32768)
+        assert cols[0][1][s] == max(max(int(lens[i]) for i in c[0][s]) for c in cols)
+    assert plan_epoch(lens, 1, 4, 512, 32768, seed=3)[0] == cols[1][0] and plan_epoch(lens, 1, 4, 512, 32768, seed=4)[0] != cols[1][0]
+    one = plan_epoch(lens, 0, 1, 512, 32768, seed=0)[0]
+    assert sorted(i for b in one for i in b) == list(range(len(lens)))
+    items = [(np.full((n, 7, 3), float(n), np.float32), np.arange(n) % 4) for n in (3, 5, 2)]
+    y, c, m, ln = pad_batch(items, pin=False)
+    assert ln == [3, 5, 2] and c.shape == (3, 5, 7, 3) and y.dtype == torch.int32
+    assert m.tolist() == [[1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 0, 0, 0]]
+    assert float(c[0, 3:].abs().sum()) == 0 and y[1].tolist() == [0, 1, 2, 3, 0] and float(c[2, 1, 6, 2]) == 2.0

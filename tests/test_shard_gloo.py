@@ -114,3 +114,36 @@ def test_flat_gradient_allreduce_two_ranks():
     mp.spawn(_grad_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for r in (0, 1):
         assert ret[r] == (1.5, 1.5, 1.5)
+
+
+def _chunk_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "rna-mpnn_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rnampnn.utils import shard
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10007, generator=g)
+    whole = flat.clone()
+    dist.all_reduce(whole); whole /= world
+    chunks = [(7000, 10007), (3000, 7000), (0, 3000)]          # backward order: tail of the model first (RNAMPNN.grad_chunks)
+    shard.allreduce_mean_chunks(flat, chunks)
+    bad = None
+    try:
+        shard.allreduce_mean_chunks(flat.clone(), [(7000, 10007), (0, 3000)])
+    except ValueError as exc:
+        bad = str(exc)
+    ret[rank] = (bool(torch.equal(flat, whole)), bad)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_gradient_allreduce_equals_one_flat_allreduce():
+    """The three chunk collectives of the overlapped exchange (bench.py train leg, rnampnn.utils.train.Trainer) give exactly the
+    average one flat all-reduce gives; ranges that do not tile the buffer are refused."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_chunk_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert ret[r][0] is True and ret[r][1] and "tile" in ret[r][1]
