@@ -72,7 +72,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--train-steps", type=int, default=-1, help="training-step leg (default: 5 at N > 1, 0 at N = 1)")
     ap.add_argument("--train-epoch", type=int, default=-1, help="config-3 epoch leg: 1 on, 0 off (default: on at N = 1 with the default workload)")
-    ap.add_argument("--recovery-steps", type=int, default=-1, help="training steps before the trained-weights recovery check (default 150 at N = 1; 0 = off)")
+    ap.add_argument("--recovery-steps", type=int, default=-1, help="training steps before the trained-weights recovery check (default 300 at N = 1; 0 = off)")
     ap.add_argument("--train-batch", type=int, default=64, help="RNAs per rank per training step")
     ap.add_argument("--no-build", action="store_true",
                     help="load the prebuilt library only (required under rocprofv3: a hipcc child of a profiled process is a forbidden exec hop)")
@@ -318,7 +318,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not dry:
             c0, m0, y0 = batches[0]
             out["cpu_baseline"] = cpu_baseline(args, hp, sd, c0, m0, y0, lens, logits, out)
-            n_rec = args.recovery_steps if args.recovery_steps >= 0 else (150 if default_cfg and args.precision == "bf16" else 0)
+            n_rec = args.recovery_steps if args.recovery_steps >= 0 else (300 if default_cfg and args.precision == "bf16" else 0)
             if n_rec > 0:
                 out["recovery"]["trained"] = guarded(lambda: trained_recovery(args, hp, sd, c0, m0, y0, lens, dev, n_rec))
         want_epoch = args.train_epoch if args.train_epoch >= 0 else int(world == 1 and default_cfg and not dry and args.precision == "bf16")

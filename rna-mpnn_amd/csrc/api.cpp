@@ -60,6 +60,7 @@ struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     size_t pq_t, pq_b;        // derived f32: [128][256] K-major (P | Q parts of Linear 0), bias [b1 | 0]
     size_t wc_t, w2_t;        // derived f32: e-part of Linear 0 and Linear 1, K-major
     size_t pq_img;            // derived bf16 [P | Q] fragment image for the fused node-update kernel
+    size_t pq_bp;             // derived f32 bias of Linear 0 in the order of that image's P rows
     size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
     size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
 };
@@ -212,6 +213,7 @@ static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     m.wc_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
     m.w2_t = add_der(c, (size_t)RN_D * RN_D * sizeof(float));
     m.pq_img = add_der(c, (size_t)64 * 1024);
+    m.pq_bp = add_der(c, RN_D * sizeof(float));
     m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
     m.b2p = add_der(c, RN_D * sizeof(float));
     return m;
@@ -244,9 +246,9 @@ extern "C" int rnampnn_create(const RnaMpnnConfig* cfg, rnampnn_handle* out) {
     if (g.padding_len < 1) return fail(RNAMPNN_ERR_BAD_ARG, "padding_len must be positive");
     if (g.precision != RNAMPNN_PREC_F32 && g.precision != RNAMPNN_PREC_BF16)
         return fail(RNAMPNN_ERR_BAD_ARG, "unknown precision %d", g.precision);
-    if (g.precision == RNAMPNN_PREC_BF16 &&
-        (g.depth_res_edge_feature != 2 || g.depth_res_mpnn != 2 || g.num_mpnn_edge_layers != 2))
-        return fail(RNAMPNN_ERR_UNSUPPORTED, "the bf16 kernels cover the default MLP depth 2 only; use precision f32");
+    if (g.precision == RNAMPNN_PREC_BF16 && (g.depth_res_edge_feature != 2 || g.depth_res_mpnn != 2))
+        return fail(RNAMPNN_ERR_UNSUPPORTED, "the bf16 kernels cover depth-2 edge-embedding / message MLPs (edge-update MLP: depth 1 or 2); "
+                    "use precision f32");
 
     rnampnn_ctx* c = new rnampnn_ctx();
     c->cfg = g;
@@ -409,9 +411,10 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
     if (m.depth > 1) launch_transpose(rawp(c, m.w[1]), RN_D, RN_D, RN_D, derp<float>(c, m.w2_t), RN_D, s);
     if (c->cfg.precision == RNAMPNN_PREC_BF16) {
         // node GEMM weights [P rows | Q rows] = W0[:, 0:128] and W0[:, 128:256], bf16 [256][128]
-        launch_build_pq_image(w0, derp<bf16_t>(c, m.pq_img), s);
-        launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
-                               derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
+        const bool one = m.depth == 1;           // (edge MLP only: rnampnn_create admits no other depth-1 MLP on this path)
+        launch_build_pq_image(w0, rawp(c, m.b[0]), one ? 1 : 0, derp<bf16_t>(c, m.pq_img), derp<float>(c, m.pq_bp), s);
+        launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, one ? nullptr : rawp(c, m.w[1]), RN_D, one ? nullptr : rawp(c, m.b[1]),
+                               is_edge ? 1 : 0, derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
     }
 }
 
@@ -552,6 +555,9 @@ static bool run_chain(Run& r, const Chain& ch, const std::vector<Lin>& layers, c
 static int run_bert(Run& r, const Bert& b, float* x, float* out) {
     rnampnn_ctx* c = r.c;
     for (auto& a : b.attn) {
+        if (r.fast && launch_attn_layer_rna(r.pk, x, derp<bf16_t>(c, a.qkv.wb), rawp(c, a.qkv.b), derp<bf16_t>(c, a.out.wb), rawp(c, a.out.b),
+                                            b.heads, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s) == 0)
+            continue;
         gemm(r, a.qkv, x, RN_D, r.w.s0, 3 * RN_D);
         if (!(r.fast && launch_attention_bf16(r.pk, r.w.s0, b.heads, r.w.n2, r.s) == 0) &&
             launch_attention_f32(r.pk, r.w.s0, b.heads, r.w.n2, r.s))
@@ -590,7 +596,7 @@ static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq, bf16_t* q)
     rnampnn_ctx* c = r.c;
     if (r.fast)     // the fused node kernel without residual / norm: P -> split-bf16 words (in pq), Q -> bf16 (in q)
         launch_node_update(r.pk, h, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, derp<bf16_t>(c, m.pq_img),
-                           derp<float>(c, m.pq_b), pq, q, nullptr, nullptr, nullptr, nullptr, r.s);
+                           derp<float>(c, m.pq_bp), pq, q, nullptr, nullptr, nullptr, nullptr, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<float>(c, m.pq_t),
                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
@@ -619,7 +625,7 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
     if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
     if (r.fast) {
         launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.q_e, r.w.pq_m,
-                         r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, r.s);
+                         r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1, r.s);
     } else {
         MpnnW32 e32 = we ? w32(c, *we) : MpnnW32{}, m32 = wm ? w32(c, *wm) : MpnnW32{};
         launch_mpnn_f32(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (float*)r.w.e, r.w.pq_e, r.w.pq_m, e32, m32,
@@ -730,7 +736,7 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
     if (!rc) {
         if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass
             launch_node_update(r.pk, w.n1, nullptr, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, w.coef, w.hA, 1,
-                               derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_b), w.pq_m, w.q_m,
+                               derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_bp), w.pq_m, w.q_m,
                                nullptr, nullptr, nullptr, nullptr, r.s);
         else
             launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, r.s);
@@ -773,8 +779,8 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
             float* p0 = need_e ? w.pq_e : w.pq_m;
             bf16_t* q0 = need_e ? w.q_e : w.q_m;
             launch_node_update(r.pk, w.hB, w.hA, gsc, gsh, t_norm, w.coef, w.hA, j1 ? 2 : 1, derp<bf16_t>(c, j0->pq_img),
-                               derp<float>(c, j0->pq_b), p0, q0, j1 ? derp<bf16_t>(c, j1->pq_img) : nullptr,
-                               j1 ? derp<float>(c, j1->pq_b) : nullptr, j1 ? w.pq_m : nullptr, j1 ? w.q_m : nullptr, s);
+                               derp<float>(c, j0->pq_bp), p0, q0, j1 ? derp<bf16_t>(c, j1->pq_img) : nullptr,
+                               j1 ? derp<float>(c, j1->pq_bp) : nullptr, j1 ? w.pq_m : nullptr, j1 ? w.q_m : nullptr, s);
         } else {
             // f32 kernels write h + agg; the bf16 kernel writes agg and the norm kernel takes the residual
             launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, gsc, gsh, t_norm, s);

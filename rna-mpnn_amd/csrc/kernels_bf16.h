@@ -27,7 +27,7 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
 // node tables: p_* f32 [N+1][128] (h.Wa^T + b1), q_* bf16 [N+1][128] (h.Wb^T; row Nmax = zeros)
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
-                      float* agg, float* msg_out, hipStream_t s);   // agg [N][128]: masked mean of the messages (no residual)
+                      float* agg, float* msg_out, bool edge1, hipStream_t s);   // agg [N][128]: masked mean of the messages (no residual); edge1: the edge MLP has one Linear
 
 // fused FFN chain  X -> Linear(K0,H)+GELU -> NH x [Linear(H,H)+GELU] -> Linear(H,NOUT)  (see kernels_bf16.hip)
 void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s);
@@ -39,10 +39,15 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
 
 // fused node update: h' = GraphNorm(x + add) (scale == null: h' = x + add, no norm), then [P | Q] projections
 // of up to two first Linears (P f32 [N][128], Q bf16 [N][128]); coef = scratch [B][256]
-void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s);
+void launch_build_pq_image(const float* w0, const float* b1, int efrag, bf16_t* dst, float* b1p, hipStream_t s);   // b1p: bias in the P-row order
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
                         float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
                         const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s);
 
 // MFMA attention over valid keys (head dim 16); returns 1 when the shape is not covered (caller uses the f32 kernel)
 int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float* out, hipStream_t s);
+
+// one whole attention layer of RNABert per RNA (QKV, attention over valid keys, out-projection + residual, GraphNorm with T_tot), in
+// place on x; returns 1 (nothing launched) unless heads == 8 and every RNA of the batch has at most 144 residues (pk.T <= 144)
+int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, const float* bqkv, const bf16_t* wout, const float* bout,
+                          int heads, const float* gscale, const float* gshift, int t_tot, hipStream_t s);

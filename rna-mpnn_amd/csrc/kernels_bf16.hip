@@ -152,6 +152,24 @@ __device__ __forceinline__ void stage_image(u32x4* __restrict__ dst, const u32x4
         for (int i = 0; i < BATCH; ++i) if (b0 + i < PER && (EXACT || tid + (b0 + i) * NT < 4096)) dst[tid + (b0 + i) * NT] = t[i];
     }
 }
+// The same copy by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, every piece of a thread in flight at once; a wave's
+// piece is 1 KiB: wave-uniform LDS base, the DMA adds lane * 16).  The caller waits with s_waitcnt vmcnt(0) + a workgroup barrier
+// before the first read (the compiler does not know these loads write LDS).  TOTAL: 16-byte units, whole waves per piece.
+#ifndef RN_NO_DMA_STAGE
+#define RN_DMA_STAGE 1
+#endif
+template <int NT, int TOTAL = 4096>
+__device__ __forceinline__ void stage_image_dma(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
+    static_assert(TOTAL % 64 == 0 && NT % 64 == 0, "whole waves per DMA piece");
+    constexpr int PER = (TOTAL + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (TOTAL % NT == 0 || tid + i * NT < TOTAL)       // (wave-uniform: NT and TOTAL are multiples of 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + i * NT),
+                                             (__attribute__((address_space(3))) void*)(dst + (tid & ~63) + i * NT), 16, 0, 0);
+}
+__device__ __forceinline__ void dma_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // x as a (hi, lo) pair of bf16 in one word (hi in the low half): x = hi + lo to ~16 bits.  Operand of the k = 2 MFMAs that
 // add a per-row constant (bias, P row) to an accumulator tile.
 __device__ __forceinline__ unsigned split_word(float x) {
@@ -205,9 +223,20 @@ void launch_convert_rows_bf16(const float* src, int ld_src, int rows, int cols, 
 //   image 1 [ob][ks][lane][8]: fragments of Linear 1; k-step ks = 2*mb + s' carries channels
 //       32mb + 16h + 8s' + j (the accumulator-as-operand order); rows (edge MLP, out_perm=1):
 //       ch_efrag order, bias permuted alike; columns (message MLP, out_perm=0): natural.
+//   depth-1 MLP (w2 == null; edge update only: e += GELU(P + Q + e Wc)): image 0 with its rows in ch_efrag order, so the
+//   accumulator tile of the ONE Linear lines up with the e fragments of the residual add; image 1 zero.
 __global__ void k_build_mlp_image(const float* __restrict__ wc, int ld_wc, const float* __restrict__ w2, int ld_w2,
                                   const float* __restrict__ b2, int out_perm, bf16_t* __restrict__ img, float* __restrict__ b2p) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;      // one element of one fragment
+    if (!w2) {
+        if (id < 2 * 32 * 64 * 8) {
+            int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
+            int r = lane & 31, h = lane >> 5, mb = f >> 3, s = f & 7;
+            img[id] = which == 0 ? f2bf(wc[(size_t)ch_efrag(mb, r) * ld_wc + 16 * s + 8 * h + j]) : (bf16_t)0;
+        }
+        if (id < 128) b2p[id] = 0.f;
+        return;
+    }
     if (id < 2 * 32 * 64 * 8) {
         int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
         int r = lane & 31, h = lane >> 5;
@@ -399,7 +428,7 @@ struct NodeTabs {             // per-residue parts of the first Linears (k_node_
 #ifndef RN_MPNN_WAVES
 #define RN_MPNN_WAVES 8           // waves per workgroup (one workgroup per CU): 2 per SIMD, <= 256 VGPRs each
 #endif
-#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 1024 + 1024 + 512 + 2048)
+#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 1024 + 1024 + 512 + 2048 + 2048)
 // Execution shape.  A block runs 16 chains - 4 channel blocks x {edge Linear 1, edge Linear 2, message Linear 1,
 // message Linear 2} - of 9-11 dependent MFMAs on a 32x32 accumulator tile, each followed by the activation
 // arithmetic of that tile ("epilogue": packed-f16 VALU).  A wave issues in order, so the two only overlap if they are
@@ -415,10 +444,13 @@ struct NodeTabs {             // per-residue parts of the first Linears (k_node_
 // against a ones column of the REAL edges (so an absent edge keeps a zero accumulator everywhere: its hidden
 // activations are 0, its e row is rewritten unchanged, its message row is GELU(bias)) - and the e fragments and
 // Q rows of the next block are requested during the last four chains of this one.
-template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT>
+// EDGE1: the edge MLP has ONE Linear (num_mpnn_edge_layers = 1, the reference's recorded alternative configuration, train.py:9-43):
+// chains 0..3 carry the residual epilogue themselves (their rows are in e-fragment order: image, P words and routing fragments are
+// built for that), chains 4..7 do not exist.
+template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT, bool EDGE1 = false>
 __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
-    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m words, 1 KiB][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB]
+    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m words, 1 KiB][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB][routing, e-fragment row order (EDGE1) 2 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
@@ -471,8 +503,13 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b0 * RN_D + 2 * lane);
         }
     }
+#ifdef RN_DMA_STAGE
+    if (DO_EDGE) stage_image_dma<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
+    if (DO_MSG) stage_image_dma<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
+#else
     if (DO_EDGE) stage_image<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
     if (DO_MSG) stage_image<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
+#endif
     if (tid < 128) {
         // The gathered Q row (bf16, fetched in the e-fragment layout: q[s] = channels 16s+8h..) is added by the MATRIX
         // pipe: two extra MFMAs per channel block whose A operand is the constant 0/1 matrix that routes channel
@@ -484,6 +521,14 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         for (int t = 0; t < 4; ++t)
             pv[t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
         lds_perm[tid] = pv;
+        if (EDGE1) {
+            // rows in ch_efrag order: row (h' = sp_r, i = c16) holds channel 16 (i >> 3) + 8 h' + (i & 7) of its 32-block
+            const bool hit = sp == (c16 >> 3) && hh == sp_r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                pv[t] = (hit && (c16 & 7) == 2 * t ? 0x3F80u : 0u) | (hit && (c16 & 7) == 2 * t + 1 ? 0x3F800000u : 0u);
+            lds_perm[128 + tid] = pv;
+        }
     }
     if (tid < 256) {
         const int blk4 = tid >> 6, rr = tid & 31, hh = (tid >> 5) & 1;
@@ -497,18 +542,22 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             lds_gb[32 * blk4 + rr] = bs * (float)phi2(cvt_h2(bs, bs))[0];
         }
     }
+#ifdef RN_DMA_STAGE
+    dma_landed();          // (the first block's e / P / index loads issued above have landed too: they are needed right after the barrier)
+#endif
     __syncthreads();
 
     const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
+    const u32x4 perm0e = EDGE1 ? lds_perm[128 + lane] : perm0, perm1e = EDGE1 ? lds_perm[192 + lane] : perm1;   // routing of the edge MLP's Q
     const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
     unsigned bwn = 0u;                                 // bias word of the NEXT chain (second Linears), requested mid-chain
     float gbv = 0.f;                                   // GELU(bias) of the channel whose mean is being formed
     if (blk >= blk_end) return;
 
     // chain sequence of a block: c = 0..3 edge Linear 1, 4..7 edge Linear 2, 8..11 message Linear 1, 12..15 message Linear 2
-    constexpr int C_FIRST = DO_EDGE ? 0 : 8, C_LAST = DO_MSG ? 15 : 7;
+    constexpr int C_FIRST = DO_EDGE ? 0 : 8, C_LAST = DO_MSG ? 15 : (EDGE1 ? 3 : 7);
 #define RN_FRAG(c, s) (((c) < 8 ? img_e : img_m)[(((c) >> 2) & 1) * 2048 + (((c) & 3) * 8 + (s)) * 64 + lane])
-#define RN_NEXT(c) ((c) == C_LAST ? C_FIRST : (c) + 1)
+#define RN_NEXT(c) ((c) == C_LAST ? C_FIRST : (EDGE1 && (c) == 3) ? 8 : (c) + 1)
 #define RN_IDX(b) ({ int i_ = (b) * npb * k + r; i_ > last_idx ? last_idx : i_; })
 #define RN_QROW(jj) ((jj) >= 0 ? ((jj) > zero_row ? zero_row : (jj)) : zero_row)
 #define RN_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -593,7 +642,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                 else if constexpr (kn == 3) bwn = lds_bwm[(cn & 3) * 64 + lane];
             }
         } else {
-            T = mfma32(i == 9 ? perm0 : perm1, q[2 * cb + (i - 9)], T);
+            if constexpr (EDGE1 && kind == 0) T = mfma32(i == 9 ? perm0e : perm1e, q[2 * cb + (i - 9)], T);
+            else T = mfma32(i == 9 ? perm0 : perm1, q[2 * cb + (i - 9)], T);
         }
     };
     // ---- the epilogue of chain c in GRANULES of ~8 vector instructions (one rides behind each MFMA of the next chain).
@@ -607,7 +657,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     auto epi_granule = [&](auto cc, auto gg, f32x16& T, int gblk, unsigned gvmask, float gcntf, float ginv) {
         constexpr int c = decltype(cc)::value, g = decltype(gg)::value;
         constexpr int kind = c >> 2, cb = c & 3;
-        constexpr int gpq = (kind & 1) ? 3 : 2;        // granules per quarter
+        constexpr bool resid = kind == 1 || (EDGE1 && kind == 0);     // this chain's output is added to e
+        constexpr int gpq = ((kind & 1) || resid) ? 3 : 2;            // granules per quarter
         constexpr int v = g / gpq, ph = g % gpq;
 #ifdef RN_EXP_NOGELU
         if constexpr (ph == 0) { gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]); gq = gx; }
@@ -627,12 +678,12 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             gq = __builtin_elementwise_fma(gq, gs, h4(0.38869277f));
             const f16x4 pp = __builtin_elementwise_fma(gx, gq, h4(0.5f));
             gq = __builtin_elementwise_min(__builtin_elementwise_max(pp, h4(0.f)), h4(1.f));      // gq now holds Phi
-            if constexpr (kind == 0 || kind == 2) {    // hidden activations -> f16 operand fragments of the second Linear
+            if constexpr ((kind == 0 && !EDGE1) || kind == 2) {    // hidden activations -> f16 operand fragments of the second Linear
                 const f16x4 gv = gx * gq;
                 hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
                 hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
             }
-        } else if constexpr (kind == 1) {              // e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
+        } else if constexpr (resid) {                  // e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
             constexpr int sp = v >> 1, t = 2 * (v & 1);
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
@@ -681,7 +732,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             }
         }
     };
-#define RN_NGRAN(c) ((((c) >> 2) & 1) ? 12 : 8)
+#define RN_NGRAN(c) (((((c) >> 2) & 1) || (EDGE1 && (c) < 4)) ? 12 : 8)
 
     // ---- prologue: state of the first block, fragments of its first chain
     j = (slot_ok && blk * npb + q0 < ntot) ? jraw_first : -1;
@@ -758,10 +809,13 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         if constexpr (DO_EDGE) {
             RN_SLOT(1, 0, true, RN_NOEXTRA); RN_SLOT(2, 1, true, RN_NOEXTRA); RN_SLOT(3, 2, true, RN_NOEXTRA);
             STAMP(t1);
-            RN_SLOT(4, 3, true, RN_EXTRA_QM); RN_SLOT(5, 4, true, RN_NOEXTRA); RN_SLOT(6, 5, true, RN_NOEXTRA); RN_SLOT(7, 6, true, RN_NOEXTRA);
+            if constexpr (!EDGE1) {
+                RN_SLOT(4, 3, true, RN_EXTRA_QM); RN_SLOT(5, 4, true, RN_NOEXTRA); RN_SLOT(6, 5, true, RN_NOEXTRA); RN_SLOT(7, 6, true, RN_NOEXTRA);
+            }
             STAMP(t2);
         }
-        if constexpr (DO_EDGE && DO_MSG) RN_SLOT(8, 7, true, RN_NOEXTRA);
+        if constexpr (DO_EDGE && DO_MSG && !EDGE1) RN_SLOT(8, 7, true, RN_NOEXTRA);
+        if constexpr (DO_EDGE && DO_MSG && EDGE1) RN_SLOT(8, 3, true, RN_EXTRA_QM);    // (the message MLP's Q rows are requested at its own first chain)
         if constexpr (DO_MSG) {
                         RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_EXTRA_E);
             STAMP(t3);
@@ -771,7 +825,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             STAMP(t5);
         } else {
             // edge update only (stand-alone API): the last epilogue rewrites e, so the next block's state cannot be requested early
-            static_for<RN_NGRAN(7)>([&](auto gg) { epi_granule(std::integral_constant<int, 7>{}, gg, RN_TILE(7), gblk, gvmask, gcntf, ginv); });
+            static_for<RN_NGRAN(C_LAST)>([&](auto gg) { epi_granule(std::integral_constant<int, C_LAST>{}, gg, RN_TILE(C_LAST), gblk, gvmask, gcntf, ginv); });
             RN_FENCE();
             jn = (slot_ok && nb_c * npb + q0 < ntot) ? jn_raw : -1;
             stage_p();
@@ -819,7 +873,7 @@ static int num_cus() { return rn_num_cus(); }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
-                      float* agg, float* msg_out, hipStream_t s) {
+                      float* agg, float* msg_out, bool edge1, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
     int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
@@ -835,16 +889,18 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     tab.dbg = dbg;
 #endif
     const bool smallk = k <= 16, mo = msg_out != nullptr;
-#define RN_LAUNCH(E, M, S, O)                                                                                  \
+#define RN_LAUNCH(E, M, S, O, E1)                                                                              \
     do {                                                                                                       \
         static DevAttr attr;                                                                                   \
-        ensure_dyn_lds((const void*)k_mpnn_bf16<E, M, S, O>, RN_MPNN_LDS, attr);                               \
-        hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O>), dim3(grid), dim3(RN_MPNN_WAVES * 64), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
+        ensure_dyn_lds((const void*)k_mpnn_bf16<E, M, S, O, E1>, RN_MPNN_LDS, attr);                           \
+        hipLaunchKernelGGL((k_mpnn_bf16<E, M, S, O, E1>), dim3(grid), dim3(RN_MPNN_WAVES * 64), lds, s, pk, k, nbr, e, tab, we, wm, agg, msg_out); \
     } while (0)
-    if (do_edge && do_msg) { if (smallk) RN_LAUNCH(true, true, true, false); else RN_LAUNCH(true, true, false, false); }
-    else if (do_edge)      { if (smallk) RN_LAUNCH(true, false, true, false); else RN_LAUNCH(true, false, false, false); }
-    else if (mo)           { if (smallk) RN_LAUNCH(false, true, true, true); else RN_LAUNCH(false, true, false, true); }
-    else                   { if (smallk) RN_LAUNCH(false, true, true, false); else RN_LAUNCH(false, true, false, false); }
+    if (do_edge && do_msg && edge1) { if (smallk) RN_LAUNCH(true, true, true, false, true); else RN_LAUNCH(true, true, false, false, true); }
+    else if (do_edge && edge1)      { if (smallk) RN_LAUNCH(true, false, true, false, true); else RN_LAUNCH(true, false, false, false, true); }
+    else if (do_edge && do_msg) { if (smallk) RN_LAUNCH(true, true, true, false, false); else RN_LAUNCH(true, true, false, false, false); }
+    else if (do_edge)      { if (smallk) RN_LAUNCH(true, false, true, false, false); else RN_LAUNCH(true, false, false, false, false); }
+    else if (mo)           { if (smallk) RN_LAUNCH(false, true, true, true, false); else RN_LAUNCH(false, true, false, true, false); }
+    else                   { if (smallk) RN_LAUNCH(false, true, true, false, false); else RN_LAUNCH(false, true, false, false, false); }
 #undef RN_LAUNCH
 #ifdef RN_STAMPS
     unsigned long long hst[8];
@@ -1182,12 +1238,24 @@ __device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4
 // one of the 8 DMA pieces of chunk c (issued between the MFMAs of the chunk that runs three chunks earlier: the ~100
 // cycles a DMA holds the wave's issue then pass under a busy matrix pipe instead of in front of it)
 __device__ __forceinline__ void chain_issue_piece(const u32x4* __restrict__ img, u32x4* ring, int c, int tid, int i) {
+#ifdef CH_EXP_NODMA       /* ablation: the weight stream stops after the prologue's three chunks (wrong results) */
+    return;
+#endif
     const u32x4* src = img + (size_t)c * 2048 + tid + i * 256;
     u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63) + i * 256;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 __device__ __forceinline__ void chain_wait(int chunks_after) {       // folded to one s_waitcnt after unrolling
+#ifdef CH_EXP_NODMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); return;
+#endif
+#ifdef CH_EXP_NOBARRIER   /* ablation: waves do not wait for each other's DMA pieces (wrong results) */
+    if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+#endif
     if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1196,49 +1264,79 @@ __device__ __forceinline__ void chain_wait(int chunks_after) {       // folded t
 
 // one Linear of the chain = NOB output blocks of NKS k-steps = NOB*NKS/32 chunks, starting at global
 // chunk C0 of NCH_T; in[] are the B fragments of its input; GELU + repack into out[] or f32 store.
+// The wave is alone on its SIMD (404 registers), so matrix and vector work only overlap if they alternate in PROGRAM order: the
+// activation arithmetic of output block ob - 1 (two accumulator tiles alternate) is cut into four granules (one per quarter of the
+// tile, ~18 packed-f16 instructions) that ride behind the MFMAs of block ob, pinned with scheduling fences - the scheme of the fused
+// ResMPNN kernel.  The last block of a layer is flushed before the next layer starts (its output is that layer's operand).
 template <int NKS, int NOB, int C0, int NCH_T, bool LAST>
 __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4* ring, int tid, int lane, int h,
                                             const u32x4 (&in)[32], u32x4 (&out)[32], const float* bias_lds,
                                             float* __restrict__ yrow, int n_valid, bool row_ok) {
     constexpr int OPC = 32 / NKS, NCH = NOB / OPC;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = C0 + ch;
+    f32x16 accA, accB;                                  // block ob accumulates in (ob & 1 ? accB : accA)
+    // quarter t of block ob's epilogue: GELU + repack into out[] (hidden layers) or the f32 store of 4 channels (last layer)
+    auto granule = [&](const f32x16& acc, auto obc, auto tc) {
+        constexpr int ob = decltype(obc)::value, t = decltype(tc)::value;
+        if constexpr (!LAST) {
+#ifdef CH_EXP_NOGELU
+            const f16x4 g = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+#else
+            const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+            const f16x4 g = x * phi4(x);           // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
+#endif
+            out[2 * ob][t] = __builtin_bit_cast(unsigned, lo2(g));
+            out[2 * ob + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+        } else if (row_ok) {
+            const int c0 = 32 * ob + 16 * h + 4 * t;
+            if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
+        }
+    };
+    static_for<NCH>([&](auto chc) {
+        constexpr int ch = decltype(chc)::value, c = C0 + ch;
         chain_wait(NCH_T - 1 - c < 2 ? NCH_T - 1 - c : 2);
         const u32x4* buf = ring + (c % CH_RING) * 2048 + lane;
         // the 32 weight fragments of the chunk go through an 8-deep register ring, so that no MFMA waits on its LDS read
         u32x4 fr[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) fr[m] = buf[m * 64];
-#pragma unroll
-        for (int o = 0; o < OPC; ++o) {
-            const int ob = ch * OPC + o;
-            f32x16 acc = init_vec16(bias_lds + 32 * ob + 16 * h);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const int m = o * NKS + ks;                    // MFMA number within the chunk (32 per chunk)
+        static_for<OPC>([&](auto oc) {
+            constexpr int o = decltype(oc)::value, ob = ch * OPC + o;
+            f32x16& acc = (ob & 1) ? accB : accA;
+            f32x16& prev = (ob & 1) ? accA : accB;
+            acc = init_vec16(bias_lds + 32 * ob + 16 * h);
+            static_for<NKS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, m = o * NKS + ks;      // m: MFMA number within the chunk (32 per chunk)
+#ifdef CH_EXP_NOMFMA      /* ablation: no matrix work (wrong results) */
+                acc[0] += __uint_as_float(fr[m & 7][0] ^ in[ks][0]);
+#else
                 acc = C0 == 0 ? mfma32(fr[m & 7], in[ks], acc) : mfma32h(fr[m & 7], in[ks], acc);    // hidden activations are f16
-                if (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
-                if (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
-            }
-            if (!LAST) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {       // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
-                    const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-                    const f16x4 g = x * phi4(x);
-                    out[2 * ob][t] = __builtin_bit_cast(unsigned, lo2(g));
-                    out[2 * ob + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
+#endif
+                if constexpr (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
+                if constexpr (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
+#ifndef CH_NO_INTERLEAVE
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ob > 0) {                        // granules of the previous block behind this block's MFMAs
+                    if constexpr (NKS >= 4) {
+                        if constexpr ((ks + 1) % (NKS / 4) == 0)
+                            granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (ks + 1) / (NKS / 4) - 1>{});
+                    } else {
+                        granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (2 * ks) & 3>{});
+                        granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (2 * ks + 1) & 3>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            } else if (row_ok) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c0 = 32 * ob + 16 * h + 4 * v;
-                    if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
-                }
-            }
+#endif
+            });
+#ifdef CH_NO_INTERLEAVE
+            static_for<4>([&](auto tc) { granule(acc, std::integral_constant<int, ob>{}, tc); });
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+#endif
+        });
+    });
+#ifndef CH_NO_INTERLEAVE
+    static_for<4>([&](auto tc) { granule(((NOB - 1) & 1) ? accB : accA, std::integral_constant<int, NOB - 1>{}, tc); });
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 template <int K0, int H, int NH, int NOUT>
@@ -1466,8 +1564,13 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RN_DMA_STAGE
+    stage_image_dma<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
+    if (NJOBS > 1) stage_image_dma<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
+#else
     stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
     if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // the biases of the P halves go through LDS too (a global read per channel block would expose an L2 round trip each)
     float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);
@@ -1493,6 +1596,11 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
         const f32x4 v0 = vx[s][0], v1 = vx[s][1];
         xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
     }
+#ifdef RN_DMA_STAGE
+    __builtin_amdgcn_sched_barrier(0);
+    dma_landed();          // (every row / coefficient load above has been consumed: only the image pieces can still be in flight; the h_out
+    __builtin_amdgcn_sched_barrier(0);     //  stores below then drain under the matrix work)
+#endif
     if (ok && h_out) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -1699,16 +1807,24 @@ __global__ void __launch_bounds__(256, 1) k_node_rna(PackInfo pk, const float* _
     }
 }
 
-// [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256]
-__global__ void k_build_pq_image(const float* __restrict__ w0, bf16_t* __restrict__ dst) {
+// [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256].
+// efrag = 1 (depth-1 edge MLP, EDGE1 of the fused kernel): the P rows - hence the P words k_node_update writes - follow ch_efrag,
+// the order of that kernel's one accumulator tile; b1p = the bias in the matching order (b1p[32 ob + 16 h + i] <-> accumulator
+// register i of lane half h).  The Q rows stay in natural channel order (the table is gathered as stored).
+__global__ void k_build_pq_image(const float* __restrict__ w0, const float* __restrict__ b1, int efrag, bf16_t* __restrict__ dst,
+                                 float* __restrict__ b1p) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= 8 * 8 * 64 * 8) return;
     int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, ob = f >> 3, ks = f & 7, r = lane & 31, h = lane >> 5;
-    int row = ch_nat(ob & 3, r), col = (ob < 4 ? 0 : 128) + 16 * ks + 8 * h + j;
+    int row = (efrag && ob < 4) ? ch_efrag(ob, r) : ch_nat(ob & 3, r), col = (ob < 4 ? 0 : 128) + 16 * ks + 8 * h + j;
     dst[id] = f2bf(w0[(size_t)row * 384 + col]);
+    if (id < 128) {
+        int ob2 = id >> 5, m = id & 31, hh = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
+        b1p[32 * ob2 + 16 * hh + i] = b1[efrag ? ch_efrag(ob2, m) : ch_nat(ob2, m)];
+    }
 }
-void launch_build_pq_image(const float* w0, bf16_t* dst, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_pq_image, dim3(8 * 8 * 64 * 8 / 256), dim3(256), 0, s, w0, dst);
+void launch_build_pq_image(const float* w0, const float* b1, int efrag, bf16_t* dst, float* b1p, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_pq_image, dim3(8 * 8 * 64 * 8 / 256), dim3(256), 0, s, w0, b1, efrag, dst, b1p);
 }
 
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
@@ -1843,6 +1959,231 @@ __global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const 
         *reinterpret_cast<f32x4*>(op) = f32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
         *reinterpret_cast<f32x4*>(op + 8) = f32x4{acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// One attention layer of RNABert (functional.py:161-169) as ONE kernel per RNA, for RNAs of at most AL_NR residues:
+//     x <- GraphNorm_P( x + out_proj( MHA(x, x, x; valid keys) ) )
+// replaces four launches (QKV GEMM, attention, out-proj GEMM + residual, GraphNorm) and three HBM round trips of [N][384] /
+// [N][128] f32 tensors by one pass: x rows in, x rows out (in place: a workgroup touches only its own RNA).  512 threads:
+//   phase 0  x -> bf16 B-fragment image in LDS                       (rows of the batch on the MFMA columns, as everywhere here)
+//   phase 1  [Q | K | V]^T = Wqkv . x^T + b, 32 x 32 tiles over the 8 waves.  The accumulator tile of a Q (K) block, packed to bf16, IS
+//            the B (A) operand of S^T = K . Q^T for its two heads - the d order inside a head is permuted identically on both sides
+//            (lane half h holds d = {4h..4h+3, 8+4h..8+4h+3}) - so Q and K go to LDS as ready fragments; V is stored transposed
+//            ([channel][key]) so that a V^T fragment is two 8-byte reads
+//   phase 2  wave = head: online softmax over the valid keys in the accumulator layout (one query per lane), O^T += V^T . P; the
+//            normalised O^T tile is again, as it stands, the B fragment of the out-projection's k-step `head` (same d permutation,
+//            applied to the weight fragment when it is loaded)
+//   phase 3  y = Wout . O^T + b + x   -> f32 rows in LDS
+//   phase 4  GraphNormalization over the RNA (two-pass statistics, padded rows enter through (P - n) mu^2), x rows out.
+// Head dim 16, 8 heads.  LDS: [A 40,960: x image, later O image | red][BC 76,032: Q, K fragments, later y][D 40,960: V^T][E: biases, coef].
+#define AL_NR 144
+#define AL_KS 160
+#define AL_YLD 132
+#define AL_LDS (40960 + 76032 + 40960 + 3072)
+#define AL_NW 16
+__global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, float* __restrict__ x, const bf16_t* __restrict__ wqkv,
+        const float* __restrict__ bqkv, const bf16_t* __restrict__ wout, const float* __restrict__ bout,
+        const float* __restrict__ gscale, const float* __restrict__ gshift, int t_tot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* Xs = reinterpret_cast<u32x4*>(smem);                                 // [rb][s][lane]; later Os [qb][head][lane]
+    u32x4* Qs = reinterpret_cast<u32x4*>(smem + 40960);                         // [head][row < AL_NR][h]
+    u32x4* Ks = Qs + 8 * AL_NR * 2;
+    float* Ys = reinterpret_cast<float*>(smem + 40960);                         // [row][AL_YLD]   (after phase 2)
+    bf16_t* Vs = reinterpret_cast<bf16_t*>(smem + 40960 + 76032);               // [channel][AL_KS keys]
+    float* lb = reinterpret_cast<float*>(smem + 40960 + 76032 + 40960);         // [384 qkv bias][128 out bias]
+    float* red = reinterpret_cast<float*>(smem);                                // [8][128] x 2   (phase 4; the O image is dead)
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0 || n > AL_NR) return;                                            // (host launches this kernel only when T <= AL_NR)
+    const int base = pk.cu[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int nrb = (n + 31) >> 5;
+    float* xb = x + (size_t)base * RN_D;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // ---- phase 0
+    if (tid < 384) lb[tid] = bqkv[tid];
+    else if (tid < 512) lb[tid] = bout[tid - 384];
+    for (int t = wave; t < nrb * 8; t += AL_NW) {
+        const int rb = t >> 3, s = t & 7, row = 32 * rb + r;
+        u32x4 v = zero4;
+        if (row < n) {
+            const float* src = xb + (size_t)row * RN_D + 16 * s + 8 * h;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src), c = *reinterpret_cast<const f32x4*>(src + 4);
+            v = u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(c[0], c[1]), pack2(c[2], c[3])};
+        }
+        Xs[t * 64 + lane] = v;
+    }
+    // ---- phase 1: tiles t = cb * nrb + rb (cb 0..11), the weight fragments of a wave's NEXT tile requested before this one's MFMAs
+    auto load_wqkv = [&](u32x4 (&af)[8], int t) {
+        const int cb = t / nrb;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const u32x4*>(wqkv + (size_t)(32 * cb + r) * RN_D + 16 * s + 8 * h);
+    };
+    u32x4 afa[8], afb[8];
+    const int nt1 = nrb * 12;
+    if (wave < nt1) load_wqkv(afa, wave);
+    __syncthreads();
+    auto qkv_tile = [&](const u32x4 (&af)[8], int t) {
+        const int cb = t / nrb, rb = t - cb * nrb;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mfma32(af[s], Xs[(rb * 8 + s) * 64 + lane], acc);
+        const int row = 32 * rb + r;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = acc[i] + lb[32 * cb + (i & 3) + 4 * h + 8 * (i >> 2)];
+        if (cb < 8) {                      // Q (scaled by 1/sqrt(16)) or K: two heads per block, ready fragments
+            const float sc = cb < 4 ? 0.25f : 1.0f;
+            u32x4* dst = cb < 4 ? Qs : Ks;
+            const int hd0 = 2 * (cb & 3);
+            if (row < AL_NR) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    dst[((hd0 + g) * AL_NR + row) * 2 + h] = u32x4{pack2(sc * v[8 * g], sc * v[8 * g + 1]), pack2(sc * v[8 * g + 2], sc * v[8 * g + 3]),
+                                                                    pack2(sc * v[8 * g + 4], sc * v[8 * g + 5]), pack2(sc * v[8 * g + 6], sc * v[8 * g + 7])};
+            }
+        } else {                           // V^T [channel][key]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Vs[(32 * (cb - 8) + (i & 3) + 4 * h + 8 * (i >> 2)) * AL_KS + row] = f2bf(v[i]);
+        }
+    };
+    for (int t = wave; t < nt1; t += 2 * AL_NW) {
+        if (t + AL_NW < nt1) load_wqkv(afb, t + AL_NW);
+        qkv_tile(afa, t);
+        if (t + AL_NW < nt1) {
+            if (t + 2 * AL_NW < nt1) load_wqkv(afa, t + 2 * AL_NW);
+            qkv_tile(afb, t + AL_NW);
+        }
+    }
+    auto load_wout = [&](u32x4 (&af)[8], int t) {       // d order of the O image: {4h..4h+3, 8+4h..8+4h+3} of head s
+        const int cb = t / nrb;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bf16_t* wp = wout + (size_t)(32 * cb + r) * RN_D + 16 * s + 4 * h;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(wp), hi = *reinterpret_cast<const u32x2*>(wp + 8);
+            af[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+    const int nt3 = nrb * 4;
+    __syncthreads();
+    // ---- phase 2: tasks (head, query block)
+    for (int task = wave; task < 8 * nrb; task += AL_NW) {
+        const int hd = task & 7, qb = task >> 3;
+        const u32x4 qf = Qs[(hd * AL_NR + min(32 * qb + r, AL_NR - 1)) * 2 + h];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float m_run = -3.0e38f, l_run = 0.f;
+        for (int kb = 0; kb < nrb; ++kb) {
+            f32x16 sc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+            sc = mfma32(Ks[(hd * AL_NR + min(32 * kb + r, AL_NR - 1)) * 2 + h], qf, sc);      // S^T[key][query]
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                sc[i] = key < n ? sc[i] : -3.0e38f;
+                mx = fmaxf(mx, sc[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float corr = __expf(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
+            l_run = l_run * corr + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= corr;
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const u32x4 pf = {pack2(sc[8 * sblk], sc[8 * sblk + 1]), pack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                  pack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), pack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                u32x4 vf = zero4;
+                if (r < 16) {
+                    const bf16_t* vp = Vs + (16 * hd + r) * AL_KS + 32 * kb + 16 * sblk + 4 * h;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vp), hi = *reinterpret_cast<const u32x2*>(vp + 8);
+                    vf = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                acc = mfma32(vf, pf, acc);                                   // O^T[d][query]
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        // d = (i & 3) + 4h + 8 (i >> 2), i < 8: this lane's k-slice of the out-projection's k-step `hd`.  (The x image in region A is dead:
+        // every wave passed the barrier behind phase 1.)
+        reinterpret_cast<u32x4*>(smem)[(qb * 8 + hd) * 64 + lane] =
+            u32x4{pack2(acc[0] * inv, acc[1] * inv), pack2(acc[2] * inv, acc[3] * inv), pack2(acc[4] * inv, acc[5] * inv), pack2(acc[6] * inv, acc[7] * inv)};
+    }
+    if (wave < nt3) load_wout(afa, wave);           // (in flight across the barrier)
+    __syncthreads();
+    // ---- phase 3: y = Wout . O^T + b + x, tiles t = cb * nrb + rb (cb 0..3)
+    auto out_tile = [&](const u32x4 (&af)[8], int t) {
+        const int cb = t / nrb, rb = t - cb * nrb;
+        const int row = 32 * rb + r;
+        const bool ok = row < n;
+        f32x4 xr[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xr[v] = *reinterpret_cast<const f32x4*>(xb + (size_t)(ok ? row : 0) * RN_D + 32 * cb + 4 * h + 8 * v);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mfma32(af[s], reinterpret_cast<const u32x4*>(smem)[(rb * 8 + s) * 64 + lane], acc);
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float* bo = lb + 384 + 32 * cb + 4 * h + 8 * v;
+                *reinterpret_cast<f32x4*>(Ys + row * AL_YLD + 32 * cb + 4 * h + 8 * v) =
+                    f32x4{acc[4 * v] + bo[0] + xr[v][0], acc[4 * v + 1] + bo[1] + xr[v][1], acc[4 * v + 2] + bo[2] + xr[v][2], acc[4 * v + 3] + bo[3] + xr[v][3]};
+            }
+        }
+    };
+    for (int t = wave; t < nt3; t += 2 * AL_NW) {
+        if (t + AL_NW < nt3) load_wout(afb, t + AL_NW);
+        out_tile(afa, t);
+        if (t + AL_NW < nt3) out_tile(afb, t + AL_NW);
+    }
+    __syncthreads();
+    // ---- phase 4: GraphNormalization over the RNA (functional.py:33-46), thread = (channel, row group of 8)
+    {
+        const int c = tid & 127, g = tid >> 7;
+        float s1 = 0.f;
+        for (int row = g; row < n; row += 8) s1 += Ys[row * AL_YLD + c];
+        red[g * 128 + c] = s1;
+        __syncthreads();
+        const float fn = (float)n;
+        float tot = red[c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) tot += red[q * 128 + c];
+        const float mu = tot / fn;
+        float s2 = 0.f;
+        for (int row = g; row < n; row += 8) { const float d = Ys[row * AL_YLD + c] - mu; s2 = fmaf(d, d, s2); }
+        red[1024 + g * 128 + c] = s2;
+        __syncthreads();
+        float sq = red[1024 + c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) sq += red[1024 + q * 128 + c];
+        const float var = (sq + (float)(t_tot - n) * mu * mu) / fn;
+        const float a = gscale[c] / sqrtf(var + kSEPS), bb = gshift[c] - mu * a;
+        for (int row = g; row < n; row += 8) xb[(size_t)row * RN_D + c] = fmaf(Ys[row * AL_YLD + c], a, bb);
+    }
+}
+
+// returns 0 when the fused per-RNA layer ran (head dim 16, 8 heads, every RNA of the batch <= AL_NR residues), 1 otherwise
+int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, const float* bqkv, const bf16_t* wout, const float* bout,
+                          int heads, const float* gscale, const float* gshift, int t_tot, hipStream_t s) {
+    static const bool off = [] { const char* e = getenv("RNAMPNN_NO_ATTN_FUSE"); return e && e[0] == '1'; }();
+    if (off || heads != 8 || pk.T > AL_NR) return 1;
+    static DevAttr attr;
+    ensure_dyn_lds((const void*)k_attn_layer_rna, AL_LDS, attr);
+    hipLaunchKernelGGL(k_attn_layer_rna, dim3(pk.B), dim3(AL_NW * 64), AL_LDS, s, pk, x, wqkv, bqkv, wout, bout, gscale, gshift, t_tot);
+    return 0;
 }
 
 // returns 0 when handled (head dim 16), 1 otherwise (the caller uses the f32 kernel)

@@ -247,15 +247,32 @@ def test_sample_and_argmax_decode():
 
 
 @pytest.mark.parametrize("name", ["c1_1b23_k16_P66", "ragged_k30", "c2_mini_k30", "c1_1b23_k30_T80", "c1_1b23_k3_default",
-                                  "phantom_n5_T8_k6", "c1_1b23_k16_P4500"])
+                                  "phantom_n5_T8_k6", "c1_1b23_k16_P4500", "alt_cfg_k4"])
 def test_bf16_path_within_tolerance(golden, name):
+    """Every golden on the bf16 fast path - incl. ``alt_cfg_k4``, the reference's recorded alternative configuration (train.py:9-43:
+    k = 4, 6 layers, ONE Linear in the edge-update MLP), which the fused kernel runs as its EDGE1 variant.  No skip: a
+    configuration the goldens cover must run on the fast path."""
     arrs, hp, shapes = golden(name)
     coords, mask = torch.from_numpy(arrs["coords"]), torch.from_numpy(arrs["mask"])
-    try:
-        model, _ = _model(hp, shapes, "bf16")
-        logits = model(coords, mask).cpu().numpy()
-    except NotImplementedError as exc:
-        pytest.skip(f"bf16 kernels unavailable for this configuration: {exc}")
+    model, _ = _model(hp, shapes, "bf16")
+    if name == "alt_cfg_k4":        # the edge tensor after layer 1 against the reference (valid slots), through the EDGE1 kernel
+        taps = model.forward_taps(coords, mask, ["e0", "e_layer", "h_layer"], tap_layer=1)
+        en = arrs["e1"].shape[1]
+        ok = arrs["edge_index"][:, :en] >= 0
+        d0 = np.abs(taps["e0"].cpu().numpy()[:, :en] - arrs["e0"])[ok]
+        d1 = np.abs(taps["e_layer"].cpu().numpy()[:, :en] - arrs["e1"])[ok]
+        dh = np.abs(taps["h_layer"].cpu().numpy() - arrs["h1"]).max()
+        print(f"alt_cfg_k4 bf16: |de0| max {d0.max():.3e} mean {d0.mean():.3e}; |de1| max {d1.max():.3e} mean {d1.mean():.3e}; |dh1| {dh:.3e}; "
+              f"max |e1| {np.abs(arrs['e1']).max():.2f}")
+        # the one-Linear edge update feeds GELU(P + Q + e Wc) straight into e (no second Linear to average the bf16 rounding of Q, e and
+        # the packed-f16 GELU out): errors of a few 1e-2 with a tail; a layout bug (wrong routing / row order) would be O(1) in SOME
+        # channels, so the per-channel mean error must be uniform
+        per_ch = np.abs(taps["e_layer"].cpu().numpy()[:, :en] - arrs["e1"])[ok].mean(0)
+        print(f"per-channel mean |de1|: min {per_ch.min():.3e} median {np.median(per_ch):.3e} max {per_ch.max():.3e}")
+        assert d1.mean() < 4e-2 and d1.max() < 0.1 * np.abs(arrs["e1"]).max(), (d1.mean(), d1.max())
+        assert per_ch.max() < 6 * np.median(per_ch) + 1e-3, (per_ch.max(), np.median(per_ch))
+        assert dh < 5e-2
+    logits = model(coords, mask).cpu().numpy()
     assert np.isfinite(logits).all()
     err = np.abs(logits - arrs["logits"]).max()
     assert err < bf16_tol(arrs["logits"], arrs["mask"]), f"{name}: |dlogit| = {err:.3e}"

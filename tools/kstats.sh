@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$1; shift; mkdir -p $OUT
 python3 $ROOT/__graft_entry__.py || exit 1    # build OUTSIDE the profiler (a hipcc child of a profiled process is a forbidden exec hop)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-build --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-build --steps 10 --warmup 3 --no-cpu-baseline --train-epoch 0 "$@" > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv, glob
 f = sorted(glob.glob("$OUT/*/*kernel_stats.csv"))[-1]

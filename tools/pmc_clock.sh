@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/$1; mkdir -p $OUT
 [ -n "$2" ] && [ "$2" != default ] && export RNAMPNN_LIB=$ROOT/rna-mpnn_amd/csrc/variants/$2.so
 python3 $ROOT/__graft_entry__.py || exit 1    # build OUTSIDE the profiler (a hipcc child of a profiled process is a forbidden exec hop)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-build --steps 2 --warmup 1 --no-cpu-baseline > $OUT/run.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-build --steps 2 --warmup 1 --no-cpu-baseline --train-epoch 0 > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob
 cc = sorted(glob.glob("$OUT/*/*counter_collection.csv"))[-1]

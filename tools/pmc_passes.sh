@@ -9,7 +9,7 @@ python3 $ROOT/__graft_entry__.py || exit 1    # build OUTSIDE the profiler (a hi
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --no-build --steps 2 --warmup 1 --no-cpu-baseline "${EXTRA[@]}" > $OUT/$name.log 2>&1
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --no-build --steps 2 --warmup 1 --no-cpu-baseline --train-epoch 0 "${EXTRA[@]}" > $OUT/$name.log 2>&1
   echo "$name exit $?"
 }
 EXTRA=("$@")
