@@ -213,6 +213,11 @@ int     rnampnn_loss_and_grad(rnampnn_handle h, const float* coords, const float
  * while the rest of the backward runs. */
 int     rnampnn_grad_chunks(rnampnn_handle h, int64_t* begin, int64_t* end);
 int     rnampnn_set_grad_events(rnampnn_handle h, void* ev0, void* ev1);
+/* hipGraph capture of a training step (the size-independent part of a small-batch step is ~600 launches): with a device seed source set,
+ * the training kernels read the dropout seed from *seed_device at kernel time (the `seed` arguments are ignored), so ONE captured
+ * rnampnn_loss_and_grad replays with fresh masks after the caller has updated the word.  No reference counterpart (the reference draws
+ * from torch's global RNG, which CUDA graphs handle by the same device-side-offset idea).  null restores the argument. */
+int     rnampnn_set_seed_source(rnampnn_handle h, const uint64_t* seed_device);
 /* Optimiser support (F2).  rnampnn_use_weight_arena: the caller's flat f32 buffer (rnampnn_grad_numel() elements, tensor i
  * at rnampnn_weight_offset(i)) becomes the library's weight storage - the nn.Parameters of the Python module are views
  * of it, so an optimiser step needs no re-upload.  rnampnn_adam_step: torch.optim.Adam (betas, eps, L2 weight decay:

@@ -52,7 +52,7 @@ struct Chain {                // fused FFN chain of the fast path (kernels_bf16.
     size_t img = 0;           // derived: fragment image of all layers
     size_t last_bias = 0;     // derived: bias of the last Linear padded to NOUT
 };
-struct Attn { Lin qkv, out; int gn_scale, gn_shift; };
+struct Attn { Lin qkv, out; int gn_scale, gn_shift; size_t img_qkv = 0, img_out = 0; };    // img_*: fragment images of the fused per-RNA layer kernel
 struct Bert { std::vector<Attn> attn; std::vector<Lin> ffn; int heads; Chain chain; };
 struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     int depth;
@@ -98,12 +98,13 @@ struct rnampnn_ctx {
     long long prof_n = 0;
     // tapes of rnampnn_train_forward calls whose backward may still come (the activations themselves live in the caller's
     // workspaces): one record per workspace, identified by a monotonically increasing id that rnampnn_train_backward must present
-    struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; };
+    struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; const unsigned long long* seed_dev; };
     std::vector<Tape> tapes;
     int64_t tape_counter = 0;
     // optional: events the backward records on its stream once a chunk of the flat gradient is final (rnampnn_grad_chunks),
     // so that the caller's all-reduce of that chunk can run on a side stream under the rest of the backward
     hipEvent_t grad_ev[2] = {nullptr, nullptr};
+    const unsigned long long* seed_dev = nullptr;   // rnampnn_set_seed_source: the training kernels read the dropout seed from device memory
     WImageCache* wimg = nullptr;   // prebuilt weight-fragment images of the bf16-mixed trainer (kernels_train.h)
     bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
     // fork / join inside one forward: independent branches of the node stack run on auxiliary streams beside the
@@ -165,6 +166,8 @@ static Bert make_bert(rnampnn_ctx* c, const std::string& prefix, int n_attn, int
         a.qkv.wt = add_der(c, (size_t)RN_D * 3 * RN_D * sizeof(float));
         a.qkv.wb = add_der(c, (size_t)RN_D * 3 * RN_D * sizeof(bf16_t));
         a.out = make_lin(c, p + ".out_proj", RN_D, RN_D, false);
+        a.img_qkv = add_der(c, (size_t)12 * 8 * 1024);
+        a.img_out = add_der(c, (size_t)4 * 8 * 1024);
         b.attn.push_back(a);
     }
     if (3 * RN_D > c->fmax && n_attn > 0) c->fmax = 3 * RN_D;
@@ -442,7 +445,11 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
     HIP_TRY(hipMemsetAsync(h->der_arena, 0, h->der_bytes, s));
     finalize_lin(h, h->raw_project, s);
     for (Bert* b : {&h->emb, &h->post}) {
-        for (auto& a : b->attn) { finalize_lin(h, a.qkv, s); finalize_lin(h, a.out, s); }
+        for (auto& a : b->attn) {
+            finalize_lin(h, a.qkv, s); finalize_lin(h, a.out, s);
+            if (h->cfg.precision == RNAMPNN_PREC_BF16)
+                launch_build_attn_images(rawp(h, a.qkv.w), rawp(h, a.out.w), derp<bf16_t>(h, a.img_qkv), derp<bf16_t>(h, a.img_out), s);
+        }
         for (auto& l : b->ffn) finalize_lin(h, l, s);
     }
     for (auto& l : h->edge_embed) finalize_lin(h, l, s);
@@ -555,7 +562,7 @@ static bool run_chain(Run& r, const Chain& ch, const std::vector<Lin>& layers, c
 static int run_bert(Run& r, const Bert& b, float* x, float* out) {
     rnampnn_ctx* c = r.c;
     for (auto& a : b.attn) {
-        if (r.fast && launch_attn_layer_rna(r.pk, x, derp<bf16_t>(c, a.qkv.wb), rawp(c, a.qkv.b), derp<bf16_t>(c, a.out.wb), rawp(c, a.out.b),
+        if (r.fast && launch_attn_layer_rna(r.pk, x, derp<bf16_t>(c, a.img_qkv), rawp(c, a.qkv.b), derp<bf16_t>(c, a.img_out), rawp(c, a.out.b),
                                             b.heads, rawp(c, a.gn_scale), rawp(c, a.gn_shift), c->cfg.padding_len, r.s) == 0)
             continue;
         gemm(r, a.qkv, x, RN_D, r.w.s0, 3 * RN_D);

@@ -49,5 +49,6 @@ int launch_attention_bf16(const PackInfo& pk, const float* qkv, int heads, float
 
 // one whole attention layer of RNABert per RNA (QKV, attention over valid keys, out-projection + residual, GraphNorm with T_tot), in
 // place on x; returns 1 (nothing launched) unless heads == 8 and every RNA of the batch has at most 144 residues (pk.T <= 144)
+void launch_build_attn_images(const float* wqkv, const float* wout, bf16_t* img_qkv, bf16_t* img_out, hipStream_t s);   // 96 KiB + 32 KiB
 int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, const float* bqkv, const bf16_t* wout, const float* bout,
                           int heads, const float* gscale, const float* gshift, int t_tot, hipStream_t s);

@@ -1981,7 +1981,33 @@ __global__ void __launch_bounds__(512) k_attention_bf16_hd16(PackInfo pk, const 
 #define AL_KS 160
 #define AL_YLD 132
 #define AL_LDS (40960 + 76032 + 40960 + 3072)
+// Fragment images of the two weights (built once per load_state_dict): 1 KiB per MFMA A fragment, lane-linear, so a wave's fragment load is
+// one coalesced 1 KiB request (row-major weights cost 64 separate 16-byte accesses per load: the QKV phase was TA-bound on them).
+//   qkv [cb 0..11][s 0..7][lane][8]: W[32 cb + r][16 s + 8 h + j];   out [cb 0..3][s 0..7][lane][8]: Wout[32 cb + r][16 s + d(h, j)],
+//   d(h, j) = j < 4 ? 4 h + j : 8 + 4 h + (j - 4) - the d order in which the attention phase leaves O^T (see the kernel).
+__global__ void k_build_attn_images(const float* __restrict__ wqkv, const float* __restrict__ wout, bf16_t* __restrict__ img_qkv,
+                                    bf16_t* __restrict__ img_out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < 12 * 8 * 64 * 8) {
+        const int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, cb = f >> 3, sft = f & 7, r = lane & 31, h = lane >> 5;
+        img_qkv[id] = f2bf(wqkv[(size_t)(32 * cb + r) * RN_D + 16 * sft + 8 * h + j]);
+    }
+    if (id < 4 * 8 * 64 * 8) {
+        const int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, cb = f >> 3, sft = f & 7, r = lane & 31, h = lane >> 5;
+        const int d = j < 4 ? 4 * h + j : 8 + 4 * h + (j - 4);
+        img_out[id] = f2bf(wout[(size_t)(32 * cb + r) * RN_D + 16 * sft + d]);
+    }
+}
+void launch_build_attn_images(const float* wqkv, const float* wout, bf16_t* img_qkv, bf16_t* img_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_attn_images, dim3(12 * 8 * 64 * 8 / 256), dim3(256), 0, s, wqkv, wout, img_qkv, img_out);
+}
 #define AL_NW 16
+#ifdef AL_STAMPS      // diagnostic build only: per-phase cycles of workgroup 0 (never shipped enabled)
+__device__ unsigned long long al_dbg[8];
+#define AL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) al_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AL_STAMP(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, float* __restrict__ x, const bf16_t* __restrict__ wqkv,
         const float* __restrict__ bqkv, const bf16_t* __restrict__ wout, const float* __restrict__ bout,
         const float* __restrict__ gscale, const float* __restrict__ gshift, int t_tot) {
@@ -2003,6 +2029,7 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     float* xb = x + (size_t)base * RN_D;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     // ---- phase 0
+    AL_STAMP(0);
     if (tid < 384) lb[tid] = bqkv[tid];
     else if (tid < 512) lb[tid] = bout[tid - 384];
     for (int t = wave; t < nrb * 8; t += AL_NW) {
@@ -2019,12 +2046,13 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     auto load_wqkv = [&](u32x4 (&af)[8], int t) {
         const int cb = t / nrb;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const u32x4*>(wqkv + (size_t)(32 * cb + r) * RN_D + 16 * s + 8 * h);
+        for (int s = 0; s < 8; ++s) af[s] = reinterpret_cast<const u32x4*>(wqkv)[(cb * 8 + s) * 64 + lane];
     };
     u32x4 afa[8], afb[8];
     const int nt1 = nrb * 12;
     if (wave < nt1) load_wqkv(afa, wave);
     __syncthreads();
+    AL_STAMP(1);
     auto qkv_tile = [&](const u32x4 (&af)[8], int t) {
         const int cb = t / nrb, rb = t - cb * nrb;
         f32x16 acc;
@@ -2037,7 +2065,7 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = acc[i] + lb[32 * cb + (i & 3) + 4 * h + 8 * (i >> 2)];
         if (cb < 8) {                      // Q (scaled by 1/sqrt(16)) or K: two heads per block, ready fragments
-            const float sc = cb < 4 ? 0.25f : 1.0f;
+            const float sc = cb < 4 ? 0.25f * 1.44269504088896f : 1.0f;      // (scores in log2 units: the softmax below uses exp2)
             u32x4* dst = cb < 4 ? Qs : Ks;
             const int hd0 = 2 * (cb & 3);
             if (row < AL_NR) {
@@ -2059,17 +2087,14 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
             qkv_tile(afb, t + AL_NW);
         }
     }
-    auto load_wout = [&](u32x4 (&af)[8], int t) {       // d order of the O image: {4h..4h+3, 8+4h..8+4h+3} of head s
+    auto load_wout = [&](u32x4 (&af)[8], int t) {       // (image built in the d order of the O image: {4h..4h+3, 8+4h..8+4h+3} of head s)
         const int cb = t / nrb;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const bf16_t* wp = wout + (size_t)(32 * cb + r) * RN_D + 16 * s + 4 * h;
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(wp), hi = *reinterpret_cast<const u32x2*>(wp + 8);
-            af[s] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
+        for (int s = 0; s < 8; ++s) af[s] = reinterpret_cast<const u32x4*>(wout)[(cb * 8 + s) * 64 + lane];
     };
     const int nt3 = nrb * 4;
     __syncthreads();
+    AL_STAMP(2);
     // ---- phase 2: tasks (head, query block)
     for (int task = wave; task < 8 * nrb; task += AL_NW) {
         const int hd = task & 7, qb = task >> 3;
@@ -2082,20 +2107,22 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
             f32x16 sc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) sc[i] = 0.f;
-            sc = mfma32(Ks[(hd * AL_NR + min(32 * kb + r, AL_NR - 1)) * 2 + h], qf, sc);      // S^T[key][query]
-            float mx = -3.0e38f;
+            sc = mfma32(Ks[(hd * AL_NR + min(32 * kb + r, AL_NR - 1)) * 2 + h], qf, sc);      // S^T[key][query], log2 units
+            if (32 * kb + 32 > n) {            // only the last key block can hold keys beyond the RNA (wave-uniform branch)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                sc[i] = key < n ? sc[i] : -3.0e38f;
-                mx = fmaxf(mx, sc[i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sc[i] = key < n ? sc[i] : -3.0e38f;
+                }
             }
+            float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float corr = __expf(m_run - m_new);
+            const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
             float ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
+            for (int i = 0; i < 16; ++i) { sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_new); ps += sc[i]; }
             l_run = l_run * corr + ps;
             m_run = m_new;
 #pragma unroll
@@ -2122,6 +2149,7 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     }
     if (wave < nt3) load_wout(afa, wave);           // (in flight across the barrier)
     __syncthreads();
+    AL_STAMP(3);
     // ---- phase 3: y = Wout . O^T + b + x, tiles t = cb * nrb + rb (cb 0..3)
     auto out_tile = [&](const u32x4 (&af)[8], int t) {
         const int cb = t / nrb, rb = t - cb * nrb;
@@ -2150,12 +2178,17 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
         if (t + AL_NW < nt3) out_tile(afb, t + AL_NW);
     }
     __syncthreads();
+    AL_STAMP(4);
     // ---- phase 4: GraphNormalization over the RNA (functional.py:33-46), thread = (channel, row group of 8)
     {
         const int c = tid & 127, g = tid >> 7;
+        constexpr int NRW = AL_NR / 8;                          // this thread's rows g, g + 8, ... stay in registers between the passes
+        float yv[NRW];
         float s1 = 0.f;
-        for (int row = g; row < n; row += 8) s1 += Ys[row * AL_YLD + c];
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) { const int row = g + 8 * q; yv[q] = row < n ? Ys[row * AL_YLD + c] : 0.f; s1 += yv[q]; }
         red[g * 128 + c] = s1;
+        const float gsc = gscale[c], gsh = gshift[c];
         __syncthreads();
         const float fn = (float)n;
         float tot = red[c];
@@ -2163,19 +2196,24 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
         for (int q = 1; q < 8; ++q) tot += red[q * 128 + c];
         const float mu = tot / fn;
         float s2 = 0.f;
-        for (int row = g; row < n; row += 8) { const float d = Ys[row * AL_YLD + c] - mu; s2 = fmaf(d, d, s2); }
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) { const float d = yv[q] - mu; s2 = (g + 8 * q < n) ? fmaf(d, d, s2) : s2; }
         red[1024 + g * 128 + c] = s2;
         __syncthreads();
         float sq = red[1024 + c];
 #pragma unroll
         for (int q = 1; q < 8; ++q) sq += red[1024 + q * 128 + c];
         const float var = (sq + (float)(t_tot - n) * mu * mu) / fn;
-        const float a = gscale[c] / sqrtf(var + kSEPS), bb = gshift[c] - mu * a;
-        for (int row = g; row < n; row += 8) xb[(size_t)row * RN_D + c] = fmaf(Ys[row * AL_YLD + c], a, bb);
+        const float a = gsc / sqrtf(var + kSEPS), bb = gsh - mu * a;
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) { const int row = g + 8 * q; if (row < n) xb[(size_t)row * RN_D + c] = fmaf(yv[q], a, bb); }
     }
+    __syncthreads();
+    AL_STAMP(5);
 }
 
-// returns 0 when the fused per-RNA layer ran (head dim 16, 8 heads, every RNA of the batch <= AL_NR residues), 1 otherwise
+// returns 0 when the fused per-RNA layer ran (head dim 16, 8 heads, every RNA of the batch <= AL_NR residues), 1 otherwise.
+// wqkv / wout: the fragment images of launch_build_attn_images.
 int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, const float* bqkv, const bf16_t* wout, const float* bout,
                           int heads, const float* gscale, const float* gshift, int t_tot, hipStream_t s) {
     static const bool off = [] { const char* e = getenv("RNAMPNN_NO_ATTN_FUSE"); return e && e[0] == '1'; }();
@@ -2183,6 +2221,15 @@ int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, cons
     static DevAttr attr;
     ensure_dyn_lds((const void*)k_attn_layer_rna, AL_LDS, attr);
     hipLaunchKernelGGL(k_attn_layer_rna, dim3(pk.B), dim3(AL_NW * 64), AL_LDS, s, pk, x, wqkv, bqkv, wout, bout, gscale, gshift, t_tot);
+#ifdef AL_STAMPS
+    {
+        unsigned long long hst[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(al_dbg), sizeof(hst));
+        fprintf(stderr, "[attn layer stamps] cycles: x image %llu | qkv %llu | attention %llu | out-proj %llu | norm %llu | total %llu\n", hst[1] - hst[0],
+                hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4], hst[5] - hst[0]);
+    }
+#endif
     return 0;
 }
 

@@ -86,6 +86,32 @@ __global__ void k_zero_regions(ZeroRegions z) {
     unsigned* p = reinterpret_cast<unsigned*>(z.ptr[g]);
     for (unsigned i = threadIdx.x; i < z.words[g]; i += blockDim.x) p[i] = 0u;
 }
+// Plain kernels instead of hipMemsetAsync / hipMemcpyAsync on the training path: inside a captured hipGraph the runtime's memset / copy
+// NODES of tens of megabytes misbehaved on this stack (NaN losses at 16 RNAs, memory faults at 64), kernel nodes do not.
+__global__ void k_zero_bytes(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s) {       // ptr 16-byte aligned
+    if (!bytes) return;
+    const size_t n16 = bytes / 16;
+    size_t g = (n16 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<uint4*>(ptr), n16,
+                       reinterpret_cast<unsigned char*>(ptr) + n16 * 16, (int)(bytes - n16 * 16));
+}
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {       // both 16-byte aligned, bytes a multiple of 16
+    const size_t n16 = bytes / 16;
+    if (!n16) return;
+    size_t g = (n16 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+}
 void launch_zero_regions(const ZeroRegions& z, hipStream_t s) {
     if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(z.n), dim3(256), 0, s, z);
 }

@@ -11,10 +11,13 @@ struct TRows { const int* ntot; int mul; int maxrows; };   // row count = *ntot 
 // 16 bits decide the even element, the high 16 bits the odd one (keep iff >= thresh = round(p * 65536)): the kernels that own 8
 // consecutive channels of a row pay 4 hashes for 8 decisions.  element index = row * D + channel with rows in the packed order
 // (node row p, edge row p*k + slot); attention: ((query row * heads + head) << 13) + key.
-struct TDrop { unsigned long long seed; unsigned thresh; float scale; };   // scale = 1/(1-p)
-static inline TDrop t_drop(float p, unsigned long long seed) {
+// seed_dev (optional): the seed is read from DEVICE memory at kernel time instead (a hipGraph that captured a training step then draws
+// fresh masks on every replay once the caller has updated *seed_dev - the decode path's rnampnn_sample_dev_seed idea).
+struct TDrop { unsigned long long seed; unsigned thresh; float scale; const unsigned long long* seed_dev; };   // scale = 1/(1-p)
+static inline TDrop t_drop(float p, unsigned long long seed, const unsigned long long* seed_dev = nullptr) {
     TDrop d;
     d.seed = seed;
+    d.seed_dev = seed_dev;
     d.thresh = p > 0.f ? (unsigned)(p * 65536.0f + 0.5f) : 0u;
     d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return d;
@@ -96,8 +99,12 @@ void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, co
 void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, const float* W, int ldw, float* dW, int ldw_out,
                   const TScratch& sc, hipStream_t s);
 // fused pair of a depth-2 MLP's backward: dW += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask   (one pass over dY and PRE)
+// `from` (optional): d pre2 is formed on the fly while the tile is staged - mode 1: dY = d e_out, d pre2 = valid ? dY gelu'(pre2) mask(site2) : 0
+// (the edge update's residual backward); mode 2: d pre2 = valid ? dagg[row / k] inv_cnt[row / k] gelu'(pre2) mask(site2) : 0 (the message mean's)
+struct EBwd2Src { int mode; const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; };
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
-                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s);
+                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from = nullptr);
+void te_inv_count(const PackInfo& pk, int k, const int* nbr, float* inv_cnt, hipStream_t s);   // 1 / max(#valid slots, 1) per residue
 void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s);
 void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);

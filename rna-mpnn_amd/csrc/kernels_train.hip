@@ -20,7 +20,8 @@ __device__ __forceinline__ float gelu_d(float x) {     // d/dx [x Phi(x)] = Phi(
 __device__ __forceinline__ int nrows(const TRows& r) { return *r.ntot * r.mul; }
 // dropout multiplier of one element: 0 or 1/(1-p) (kernels_train.h: TDrop; restated by the oracle's dropout_multiplier).
 __device__ __forceinline__ unsigned drop_key(const TDrop& d, unsigned site) {         // wave-uniform part of the hash input
-    return site * 0x85EBCA6Bu + (unsigned)d.seed + (unsigned)(d.seed >> 32) * 0x27D4EB2Fu;
+    const unsigned long long sd = d.seed_dev ? *d.seed_dev : d.seed;
+    return site * 0x85EBCA6Bu + (unsigned)sd + (unsigned)(sd >> 32) * 0x27D4EB2Fu;
 }
 __device__ __forceinline__ unsigned drop_hash(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu;
@@ -456,7 +457,7 @@ __global__ void k_rev_rank(PackInfo pk, const int* __restrict__ nbr, const int* 
     }
 }
 void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, int* tmp, hipStream_t s) {
-    (void)hipMemsetAsync(deg, 0, (size_t)pk.Nmax * sizeof(int), s);
+    launch_zero_bytes(deg, (size_t)pk.Nmax * sizeof(int), s);
     size_t E = (size_t)pk.Nmax * k;
     unsigned g = (unsigned)((E + 255) / 256); if (g > 8192) g = 8192; if (g < 1) g = 1;
     hipLaunchKernelGGL(k_rev_count, dim3(g), dim3(256), 0, s, pk, k, nbr, deg);
@@ -2003,9 +2004,15 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d) {   
     g = x * sg;
     d = fmaf(x * 0.3989422804f, __builtin_amdgcn_exp2f(x * x * -0.72134752f), sg);
 }
+// MODE: where d pre2 comes from.  0: the tensor dY.  1 (edge update, mpnn.py:250-262): d pre2 = valid ? dY * gelu'(PRE2) * mask(site2) : 0 with
+// dY = d e_out - the residual backward formed while the tile is staged instead of by a kernel of its own (one read and one write of an
+// [E][128] tensor less).  2 (message mean, mpnn.py:212-219): d pre2 = valid ? dagg[row / k] / cnt[row / k] * gelu'(PRE2) * mask(site2) : 0.
+// The staged values are rounded to bf16 exactly as the stand-alone kernels stored them: results are bit-identical to the two-kernel form.
+struct Bwd2Src { const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; };
+template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __restrict__ dY, const tb16* __restrict__ PRE, tb16* __restrict__ DX,
         const float* __restrict__ W, int ldw, const unsigned short* __restrict__ wimg, float* __restrict__ part, size_t pstride,
-        int rows_per_split, TDrop dr, unsigned site, float* __restrict__ cs_part) {
+        int rows_per_split, TDrop dr, unsigned site, float* __restrict__ cs_part, Bwd2Src src) {
     __shared__ __attribute__((aligned(16))) unsigned short tA[64 * TN_PITCH], tB[64 * TN_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short tG[32 * 64 * 8];          // W2 image (32 KiB) first, then the g' tile [64][TN_PITCH]
     float (*cs_red)[128] = reinterpret_cast<float (*)[128]>(tA);
@@ -2025,13 +2032,16 @@ __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __r
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
         for (int u = 0; u < 2; ++u) wf[ks][u] = reinterpret_cast<const tu32x4*>(tG)[(ks * 4 + 2 * wc + u) * 64 + lane];
+    const unsigned key2 = drop_key(dr, src.site2);
+    tu32x4 c0[MODE == 1 ? 4 : 1];                             // MODE 1: the taped pre2 chunk (MODE 2 carries it in the dY slot)
     auto load_tile = [&](int m0, tu32x4 (&xa)[4], tu32x4 (&xb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + rg + 16 * i;
             const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
-            xa[i] = *reinterpret_cast<const tu32x4*>(dY + (size_t)mc * 128 + 8 * ch);
+            xa[i] = *reinterpret_cast<const tu32x4*>((MODE == 2 ? src.pre2 : dY) + (size_t)mc * 128 + 8 * ch);
             xb[i] = *reinterpret_cast<const tu32x4*>(PRE + (size_t)mc * 128 + 8 * ch);
+            if constexpr (MODE == 1) c0[i] = *reinterpret_cast<const tu32x4*>(src.pre2 + (size_t)mc * 128 + 8 * ch);
         }
     };
     tf32x16 acc[2][2];
@@ -2046,11 +2056,47 @@ __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __r
     if (m0 < p_end) load_tile(m0, a0, b0);
     while (m0 < p_end) {
         __syncthreads();                                      // the previous tile's fragment reads (and, first time, the image reads) are done
+        tu32x4 dy4[4];                                        // d pre2 of this thread's four chunks
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dy4[i] = a0[i];
+        } else {
+            int jv[4];
+            tf32x4 ga[MODE == 2 ? 4 : 1], gb[MODE == 2 ? 4 : 1];
+            float ic[MODE == 2 ? 4 : 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                     // (all loads of the phase first)
+                const int m = m0 + rg + 16 * i;
+                const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+                jv[i] = src.nbr[mc];
+                if constexpr (MODE == 2) {
+                    const int res = mc / src.k;
+                    ga[i] = *reinterpret_cast<const tf32x4*>(src.dagg + (size_t)res * 128 + 8 * ch);
+                    gb[i] = *reinterpret_cast<const tf32x4*>(src.dagg + (size_t)res * 128 + 8 * ch + 4);
+                    ic[i] = src.inv_cnt[res];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + rg + 16 * i;
+                float up[8], p2[8], dm2[8];
+                if constexpr (MODE == 1) { unpack8(a0[i], up); unpack8(c0[i], p2); }
+                else {
+                    unpack8(a0[i], p2);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { up[q] = ga[i][q] * ic[i]; up[4 + q] = gb[i][q] * ic[i]; }
+                }
+                drop8(dr, key2, (unsigned)m * 16u + ch, dm2);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) up[q] = MODE == 1 ? up[q] * (gelu_d_fast(p2[q]) * dm2[q]) : up[q] * gelu_d_fast(p2[q]) * dm2[q];   // (the stand-alone kernels' association)
+                dy4[i] = jv[i] >= 0 ? tpack8(up) : z4;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + rg + 16 * i;
             const bool ok = m < p_end;
-            const tu32x4 va = ok ? a0[i] : z4;
+            const tu32x4 va = ok ? dy4[i] : z4;
             float v[8], dm[8], a1[8], gp[8];
             unpack8(b0[i], v);
             drop8(dr, key, (unsigned)m * 16u + ch, dm);
@@ -2256,7 +2302,7 @@ void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, co
 }
 // dW[128][ldw_out] += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask        (W [128 out][ldw] as nn.Linear stores it)
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
-                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
+                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from) {
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
     int splits = (rows.maxrows + 511) / 512;                 // >= 8 tiles per workgroup; fills the chip from ~130 K rows on
@@ -2267,8 +2313,13 @@ void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, 
     const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
     const size_t pstride = mk + (dbias ? 128 : 0);
     float* tmp = sc.p + (size_t)splits * pstride;
-    hipLaunchKernelGGL(k_emm_bwd2, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, PRE, DX, W, ldw, wimg_lookup(W, ldw, false, 1), sc.p, pstride,
-                       rps, dr, site, dbias ? sc.p + mk : (float*)nullptr);
+    Bwd2Src src{nullptr, nullptr, nullptr, nullptr, 1, 0u};
+    const int mode = from ? from->mode : 0;
+    if (from) src = Bwd2Src{from->pre2, from->nbr, from->dagg, from->inv_cnt, from->k, from->site2};
+#define BWD2_GO(M) hipLaunchKernelGGL(k_emm_bwd2<M>, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, PRE, DX, W, ldw, wimg_lookup(W, ldw, false, 1), \
+                                       sc.p, pstride, rps, dr, site, dbias ? sc.p + mk : (float*)nullptr, src)
+    if (mode == 1) BWD2_GO(1); else if (mode == 2) BWD2_GO(2); else BWD2_GO(0);
+#undef BWD2_GO
     reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw_out, s, tmp, (int)mk, dbias);
 }
 
@@ -2321,6 +2372,17 @@ __global__ void __launch_bounds__(256) k_eseg_mean_bwd(PackInfo pk, int k, const
         const unsigned o = tpack2(g0 * gelu_d_fast(tbf_lo(w)) * m0, g1 * gelu_d_fast(tbf_hi(w)) * m1);
         *reinterpret_cast<unsigned*>(obase + (size_t)sl * RN_D) = valid ? o : 0u;
     }
+}
+// 1 / max(#valid neighbour slots, 1) per residue: the k-NN graph is fixed across the layers, the mean's backward needs it per edge row
+__global__ void k_inv_count(PackInfo pk, int k, const int* __restrict__ nbr, float* __restrict__ inv_cnt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pk.cu[pk.B]) return;
+    int cnt = 0;
+    for (int sl = 0; sl < k; ++sl) cnt += nbr[(size_t)p * k + sl] >= 0;
+    inv_cnt[p] = 1.0f / (float)(cnt > 0 ? cnt : 1);
+}
+void te_inv_count(const PackInfo& pk, int k, const int* nbr, float* inv_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_inv_count, dim3((pk.Nmax + 255) / 256), dim3(256), 0, s, pk, k, nbr, inv_cnt);
 }
 void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s) {
     hipLaunchKernelGGL(k_eseg_mean, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, pre2, h, out, dr, site);

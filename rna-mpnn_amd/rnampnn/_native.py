@@ -72,6 +72,7 @@ SYMBOLS = {
     "rnampnn_train_forward": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _SZ, _VP, C.POINTER(_I64)]),
     "rnampnn_grad_chunks": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "rnampnn_set_grad_events": (C.c_int, [_VP, _VP, _VP]),
+    "rnampnn_set_seed_source": (C.c_int, [_VP, _VP]),
     "rnampnn_use_weight_arena": (C.c_int, [_VP, _VP, _VP]),
     "rnampnn_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _F, _F, _F, _F, _F, _I32, _VP]),
     "rnampnn_train_backward": (C.c_int, [_VP, _I64, _VP, _I32, _I32, _I32, _VP, _VP, _SZ, _VP]),

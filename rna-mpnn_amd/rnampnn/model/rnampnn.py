@@ -652,3 +652,68 @@ class CapturedSampler:
         self.seed.fill_(int(seed) & (2 ** 63 - 1))
         self.graph.replay()
         return self.logits, self.samples
+
+
+class CapturedTrainStep:
+    """hipGraph-captured training step for a fixed (B, T) bucket: ONE graph launch replays the whole taped forward + HIP backward
+    (``rnampnn_loss_and_grad``, ~600 kernel launches at the default depth), so a small batch is no longer bound by launch overhead.
+    Inputs are copied into static device buffers; the dropout seed lives in device memory (``rnampnn_set_seed_source``), so every
+    replay draws fresh masks.  The gradient lands in ``model.flat_grad`` as in the eager path; the gradient exchange and the
+    optimiser step stay outside the graph (Adam's bias correction is a host-side step count).  The tape workspace is private
+    to this object.  ``torch.cuda.CUDAGraph`` is capture / replay plumbing only: every node is a kernel of ``librnampnn_hip.so``."""
+
+    def __init__(self, model: RNAMPNN, B: int, T: int, T_norm: int = 0, dropout: Optional[float] = None):
+        self.model, self.B, self.T, self.T_norm = model, int(B), int(T), int(T_norm)
+        device = model._ensure(for_mixed_training=model.train_precision == "bf16")
+        self.device = device
+        self.p = float(model._hp["dropout"] if dropout is None else dropout)
+        self.labels = torch.zeros(B, T, dtype=torch.int32, device=device)
+        self.coords = torch.zeros(B, T, 7, 3, dtype=torch.float32, device=device)
+        self.mask = torch.zeros(B, T, dtype=torch.float32, device=device)
+        self.mask[:, 0] = 1
+        self.seed = torch.zeros(1, dtype=torch.int64, device=device)
+        self.loss = torch.zeros((), dtype=torch.float32, device=device)
+        self._slot, self._lease = model._tape_slot(B, T, device, lease=True)          # held for the life of this object
+        model._bind_flat_grad(device)
+        self._grad_ptr, self._arena_ptr = model.flat_grad.data_ptr(), model._flat_param.data_ptr()
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):               # warm-up: weight-image registration, one-time function attributes
+            for _ in range(2):
+                self._launch()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._launch()
+
+    def _launch(self):
+        m, lib = self.model, _native.lib()
+        with torch.cuda.device(self.device):
+            _native.check(lib.rnampnn_set_seed_source(m._handle.ptr, _ptr(self.seed)))
+            _native.check(lib.rnampnn_set_grad_events(m._handle.ptr, None, None))      # (no event records inside a capture)
+            try:
+                ws, ws_bytes = m._ws_ptr(self._slot)
+                _native.check(lib.rnampnn_loss_and_grad(m._handle.ptr, _ptr(self.coords), _ptr(self.mask), _ptr(self.labels), self.B, self.T,
+                                                        self.T_norm, self.p, C.c_uint64(0), m._train_flags(), _ptr(self.loss), None,
+                                                        _ptr(m.flat_grad), ws, ws_bytes, _stream(self.device)))
+            finally:
+                _native.check(lib.rnampnn_set_seed_source(m._handle.ptr, None))
+                ar = getattr(m, "_ar", None)
+                if ar is not None:
+                    _native.check(lib.rnampnn_set_grad_events(m._handle.ptr, C.c_void_p(ar["events"][0].cuda_event), C.c_void_p(ar["events"][1].cuda_event)))
+
+    def __call__(self, labels: torch.Tensor, coords: torch.Tensor, mask: torch.Tensor, seed: int) -> torch.Tensor:
+        """-> device loss (static tensor, overwritten by the next call); ``model.flat_grad`` / every ``p.grad`` hold the gradient."""
+        m = self.model
+        device = m._ensure(for_mixed_training=m.train_precision == "bf16")
+        m._bind_flat_grad(device)
+        if m.flat_grad.data_ptr() != self._grad_ptr or m._flat_param.data_ptr() != self._arena_ptr:
+            raise RuntimeError("CapturedTrainStep: the model's flat parameter / gradient buffer moved after the capture; build a new one")
+        lab = labels.argmax(dim=-1) if labels.dim() == 3 else labels
+        self.labels.copy_(lab, non_blocking=True)
+        self.coords.copy_(coords, non_blocking=True)
+        self.mask.copy_(mask, non_blocking=True)
+        self.seed.fill_(int(seed) & (2 ** 63 - 1))
+        self.graph.replay()
+        return self.loss

@@ -179,3 +179,24 @@ def test_matched_recovery_on_trained_logits_64_rnas():
     assert out["loss_last"] < out["loss_first"]
     assert out["argmax_agreement"] >= 0.99, out
     assert abs(out["recovery_bf16_hip"] - out["recovery_f32_oracle"]) <= 0.005, out
+
+
+def test_captured_train_step_equals_eager_and_draws_fresh_masks():
+    """hipGraph-captured training step (device-side dropout seed): replay == the eager rnampnn_loss_and_grad with the same seed,
+    bit for bit (loss and every gradient); another seed gives other masks; the weights the replay sees follow the optimiser."""
+    from rnampnn.model.rnampnn import CapturedTrainStep
+    from rnampnn.utils import synth
+    model = _small("bf16", num_res_mpnn_layers=3)
+    c, m, y = (torch.from_numpy(x).cuda() for x in synth.synth_batch([24, 17, 30, 12], first_index=70))
+    (opt,), _ = model.configure_optimizers(fused=True)
+    eager = model.loss_and_grad(y, c, m, seed=4242).clone()
+    g_eager = model.flat_grad.clone()
+    cap = CapturedTrainStep(model, 4, 30)
+    l1 = cap(y, c, m, seed=4242).clone()
+    assert torch.equal(model.flat_grad, g_eager) and float(l1) == float(eager)
+    l2 = cap(y, c, m, seed=4243).clone()
+    assert float(l2) != float(l1) and not torch.equal(model.flat_grad, g_eager)
+    opt.step()                                              # weights change in place: the replay reads the updated arena
+    l3 = cap(y, c, m, seed=4242).clone()
+    e3 = model.loss_and_grad(y, c, m, seed=4242)
+    assert float(l3) == float(e3) and float(l3) != float(l1)
