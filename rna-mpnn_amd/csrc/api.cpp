@@ -632,7 +632,8 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
     if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
     if (r.fast) {
         launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.q_e, r.w.pq_m,
-                         r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1, r.s);
+                         r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1,
+                         wm ? h_in : nullptr, r.s);      // h_pre = h_in + mean of the messages (both paths)
     } else {
         MpnnW32 e32 = we ? w32(c, *we) : MpnnW32{}, m32 = wm ? w32(c, *wm) : MpnnW32{};
         launch_mpnn_f32(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (float*)r.w.e, r.w.pq_e, r.w.pq_m, e32, m32,
@@ -780,17 +781,17 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
         const float* gsc = rawp(c, c->mpnn[l].gn_scale);
         const float* gsh = rawp(c, c->mpnn[l].gn_shift);
         if (r.fast && (need_e || need_m)) {
-            // the bf16 kernel wrote agg; residual + GraphNorm + both [P | Q] projections in one kernel
+            // the bf16 kernel wrote h + agg; GraphNorm + both [P | Q] projections in one kernel
             const Mlp2* j0 = need_e ? &c->mpnn[l].edge : &c->mpnn[l + 1].msg;
             const Mlp2* j1 = (need_e && need_m) ? &c->mpnn[l + 1].msg : nullptr;
             float* p0 = need_e ? w.pq_e : w.pq_m;
             bf16_t* q0 = need_e ? w.q_e : w.q_m;
-            launch_node_update(r.pk, w.hB, w.hA, gsc, gsh, t_norm, w.coef, w.hA, j1 ? 2 : 1, derp<bf16_t>(c, j0->pq_img),
+            launch_node_update(r.pk, w.hB, nullptr, gsc, gsh, t_norm, w.coef, w.hA, j1 ? 2 : 1, derp<bf16_t>(c, j0->pq_img),
                                derp<float>(c, j0->pq_bp), p0, q0, j1 ? derp<bf16_t>(c, j1->pq_img) : nullptr,
                                j1 ? derp<float>(c, j1->pq_bp) : nullptr, j1 ? w.pq_m : nullptr, j1 ? w.q_m : nullptr, s);
         } else {
-            // f32 kernels write h + agg; the bf16 kernel writes agg and the norm kernel takes the residual
-            launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, gsc, gsh, t_norm, s);
+            // (both kernel families write h + agg)
+            launch_graph_norm_packed(r.pk, w.hB, nullptr, w.hA, gsc, gsh, t_norm, s);
             if (need_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e, w.q_e);
             if (need_m) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m, w.q_m);
         }
@@ -885,7 +886,7 @@ extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* 
     mpnn_step(r, nullptr, &m.msg, w.hA, w.hB, msg_p);
     if (msg_out) launch_unpack_edges(r.pk, k, w.big, nullptr, msg_out, s);
     if (h_out || e_out) {
-        launch_graph_norm_packed(r.pk, w.hB, r.fast ? w.hA : nullptr, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
+        launch_graph_norm_packed(r.pk, w.hB, nullptr, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
         if (h_out) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, h_out, s);
         if (e_out) {
             node_pq(r, m.edge, w.hA, w.pq_e, w.q_e);

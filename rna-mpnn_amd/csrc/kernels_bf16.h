@@ -27,7 +27,7 @@ void launch_edge_embed_bf16(const PackInfo& pk, int k, const float* geom, const 
 // node tables: p_* f32 [N+1][128] (h.Wa^T + b1), q_* bf16 [N+1][128] (h.Wb^T; row Nmax = zeros)
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
-                      float* agg, float* msg_out, bool edge1, hipStream_t s);   // agg [N][128]: masked mean of the messages (no residual); edge1: the edge MLP has one Linear
+                      float* agg, float* msg_out, bool edge1, const float* h_res, hipStream_t s);   // agg [N][128]: h_res + masked mean of the messages (h_res null: the mean alone); edge1: the edge MLP has one Linear
 
 // fused FFN chain  X -> Linear(K0,H)+GELU -> NH x [Linear(H,H)+GELU] -> Linear(H,NOUT)  (see kernels_bf16.hip)
 void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s);

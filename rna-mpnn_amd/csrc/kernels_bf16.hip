@@ -422,13 +422,15 @@ struct NodeTabs {             // per-residue parts of the first Linears (k_node_
     const bf16_t* q_e;        // [N+1][128] bf16  h.Wb_e^T         (row N = zeros)
     const unsigned* p_m;
     const bf16_t* q_m;
+    const float* h_res;       // [N][128] f32 or null: the residue's h, added to the mean so that the launch writes h + agg (mpnn.py:222): the
+                              // statistics and update kernels behind it then read ONE node tensor instead of two
     unsigned long long* dbg;  // RN_STAMPS diagnostic buffer (null otherwise)
 };
 
 #ifndef RN_MPNN_WAVES
 #define RN_MPNN_WAVES 8           // waves per workgroup (one workgroup per CU): 2 per SIMD, <= 256 VGPRs each
 #endif
-#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1024 + 1024 + 1024 + 512 + 2048 + 2048)
+#define RN_MPNN_LDS (131072 + RN_MPNN_WAVES * 1536 + 1024 + 1024 + 512 + 2048 + 2048)
 // Execution shape.  A block runs 16 chains - 4 channel blocks x {edge Linear 1, edge Linear 2, message Linear 1,
 // message Linear 2} - of 9-11 dependent MFMAs on a 32x32 accumulator tile, each followed by the activation
 // arithmetic of that tile ("epilogue": packed-f16 VALU).  A wave issues in order, so the two only overlap if they are
@@ -450,14 +452,14 @@ struct NodeTabs {             // per-residue parts of the first Linears (k_node_
 template <bool DO_EDGE, bool DO_MSG, bool SMALLK, bool MSGOUT, bool EDGE1 = false>
 __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         NodeTabs tab, MpnnWB we, MpnnWB wm, float* __restrict__ agg, float* __restrict__ msg_out) {
-    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m words, 1 KiB][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB][routing, e-fragment row order (EDGE1) 2 KiB]
+    // LDS: [img_e 64 KiB][img_m 64 KiB][per wave: P_e | P_m words | h row, 1.5 KiB][bias words edge 1 KiB][bias words msg 1 KiB][GELU(bias) msg 512 B][routing 2 KiB][routing, e-fragment row order (EDGE1) 2 KiB]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
     constexpr int NW = RN_MPNN_WAVES;
     const int tid = threadIdx.x;
-    unsigned* lds_p = reinterpret_cast<unsigned*>(smem + 131072) + (tid >> 6) * 256;
-    unsigned* lds_bwe = reinterpret_cast<unsigned*>(smem + 131072) + NW * 256;  // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
+    unsigned* lds_p = reinterpret_cast<unsigned*>(smem + 131072) + (tid >> 6) * 384;
+    unsigned* lds_bwe = reinterpret_cast<unsigned*>(smem + 131072) + NW * 384;  // [ob][lane]: (hi, lo) bf16 split of the bias of accumulator row lane&31
     unsigned* lds_bwm = lds_bwe + 256;                                          // [nb][lane]: same for output channel 32nb + (lane&31)
     float* lds_gb = reinterpret_cast<float*>(lds_bwm + 256);                    // [nb][r]: GELU(bias), as the epilogue computes it
     u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_gb + 128);                   // [2][lane]: constant 0/1 routing fragments
@@ -489,6 +491,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     u32x4 ef[8];
     u32x2 pn_e = {0u, 0u}, pn_m = {0u, 0u};
+    f32x2 hn = {0.f, 0.f};                            // the block's h row (two channels per lane), staged like the P words
     int jraw_first = -1;
     if (nblocks > 0) {
         const int b0 = blk < blk_end ? blk : 0;
@@ -501,6 +504,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         if (!SMALLK) {
             if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b0 * RN_D + 2 * lane);
             if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b0 * RN_D + 2 * lane);
+            if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b0 * RN_D + 2 * lane);
         }
     }
 #ifdef RN_DMA_STAGE
@@ -581,11 +585,13 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         if (SMALLK) return;
         if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + 2 * lane);
         if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + 2 * lane);
+        if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b * RN_D + 2 * lane);
     };
     auto stage_p = [&]() {                             // ... through the wave's LDS slot ...
         if (SMALLK) return;
         if (DO_EDGE) *reinterpret_cast<u32x2*>(lds_p + 2 * lane) = pn_e;
         if (DO_MSG) *reinterpret_cast<u32x2*>(lds_p + 128 + 2 * lane) = pn_m;
+        if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 256 + 2 * lane) = hn;
     };
     auto fetch_p = [&]() {                             // ... back as this lane's four words per MLP
         if (SMALLK) return;
@@ -653,6 +659,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     // residual add and bf16 repack of e, or the running sum of the mean).  g* = context of the block the chain belongs to.
     static_assert(RN_PHI_DEG == 4, "the granule form of the epilogue implements the 4-coefficient Phi");
     float s0 = 0.f, s1 = 0.f;
+    float ghres[4] = {0.f, 0.f, 0.f, 0.f};           // h of the block whose message epilogues are running (channel 32 cb + r)
     f16x4 gx = h4(0.f), gs = h4(0.f), gq = h4(0.f);    // state carried between the granules of a quarter
     auto epi_granule = [&](auto cc, auto gg, f32x16& T, int gblk, unsigned gvmask, float gcntf, float ginv) {
         constexpr int c = decltype(cc)::value, g = decltype(gg)::value;
@@ -702,7 +709,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                 float sum = s0 + s1;
                 sum += __shfl_xor(sum, 32, 64);
                 // both lane halves hold the total: the duplicate store of half 1 saves a divergent branch
-                agg[(size_t)gblk * RN_D + 32 * cb + r] = (sum - gcntf * gbv) * ginv;
+                agg[(size_t)gblk * RN_D + 32 * cb + r] = fmaf(sum - gcntf * gbv, ginv, ghres[cb]);
             }
         } else {                                       // several residues per block / per-edge message output
             T[4 * v] *= (float)gq[0]; T[4 * v + 1] *= (float)gq[1]; T[4 * v + 2] *= (float)gq[2]; T[4 * v + 3] *= (float)gq[3];
@@ -727,7 +734,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                         sum = fmaf(T[i], (float)((segh >> ((i & 3) + 8 * (i >> 2))) & 1u), sum);
                     sum += __shfl_xor(sum, 32, 64);
                     const int cnt = __popc(seg);
-                    if (h == 0) agg[(size_t)node * RN_D + 32 * cb + r] = sum / (float)(cnt > 0 ? cnt : 1);
+                    if (h == 0) agg[(size_t)node * RN_D + 32 * cb + r] = sum / (float)(cnt > 0 ? cnt : 1) + (tab.h_res ? tab.h_res[(size_t)node * RN_D + 32 * cb + r] : 0.f);
                 }
             }
         }
@@ -792,6 +799,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             const int cnt_all = __popc(vmask);
             gblk = blk; gvmask = vmask; gcntf = (float)(32 - cnt_all);
             ginv = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
+            if (DO_MSG && !SMALLK && !MSGOUT) {       // (the wave's slot still holds THIS block's row: the next one is staged behind chain 12)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) ghres[mb] = __uint_as_float(lds_p[256 + 32 * mb + r]);
+            }
         }
         int jn = -1;
         // requests for the next block: its e fragment s as soon as the last reader of ef[s] - k-step s of the last message
@@ -873,7 +884,7 @@ static int num_cus() { return rn_num_cus(); }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
                       const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
-                      float* agg, float* msg_out, bool edge1, hipStream_t s) {
+                      float* agg, float* msg_out, bool edge1, const float* h_res, hipStream_t s) {
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
     int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
@@ -881,7 +892,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
     size_t lds = RN_MPNN_LDS;
-    NodeTabs tab{reinterpret_cast<const unsigned*>(p_e), q_e, reinterpret_cast<const unsigned*>(p_m), q_m, nullptr};
+    NodeTabs tab{reinterpret_cast<const unsigned*>(p_e), q_e, reinterpret_cast<const unsigned*>(p_m), q_m, h_res, nullptr};
 #ifdef RN_STAMPS
     static unsigned long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc((void**)&dbg, 64);

@@ -31,22 +31,31 @@ __global__ void k_lengths(const float* __restrict__ mask, int B, int T, int* __r
     if (threadIdx.x == 0) len[b] = (int)(s + 0.5f);
 }
 
+// exclusive prefix sum of one int per thread over a 1024-thread workgroup (wave shuffles + one LDS hop); *total = the grand sum
+// (a serial loop of thread 0 over 1024 LDS words took 10 us of every forward)
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wave_tot /* LDS [16] */, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int t = wave_tot[w]; if (w < wave) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
 __global__ void __launch_bounds__(1024) k_scan(const int* __restrict__ len, int B, int* __restrict__ cu) {
-    __shared__ int part[1024];
+    __shared__ int wave_tot[16];
     int tid = threadIdx.x;
     int chunk = (B + 1023) / 1024;
-    int lo = tid * chunk, hi = min(B, lo + chunk);
+    int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
     int s = 0;
     for (int i = lo; i < hi; ++i) s += len[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { int v = part[i]; part[i] = run; run += v; }
-        cu[B] = run;
-    }
-    __syncthreads();
-    int run = part[tid];
+    int total;
+    int run = block_exclusive_scan_1024(s, wave_tot, &total);
+    if (tid == 0) cu[B] = total;
     for (int i = lo; i < hi; ++i) { cu[i] = run; run += len[i]; }
 }
 
@@ -56,21 +65,15 @@ __global__ void __launch_bounds__(1024) k_scan(const int* __restrict__ len, int 
 // running total to N_total - results for an out-of-contract input are meaningless, but memory-safe.
 __global__ void __launch_bounds__(1024) k_lengths_from_cu(const int32_t* __restrict__ cu_in, int B, int T, int Nmax,
                                                           int* __restrict__ len, int* __restrict__ cu) {
-    __shared__ int part[1024];
+    __shared__ int wave_tot[16];
     const int tid = threadIdx.x;
     const int chunk = (B + 1023) / 1024;
     const int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
     int s = 0;
     for (int i = lo; i < hi; ++i) s += min(max(cu_in[i + 1] - cu_in[i], 0), T);
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 1024; ++i) { int v = part[i]; part[i] = run; run += v; }
-        cu[B] = min(run, Nmax);
-    }
-    __syncthreads();
-    int run = part[tid];
+    int total;
+    int run = block_exclusive_scan_1024(s, wave_tot, &total);
+    if (tid == 0) cu[B] = min(total, Nmax);
     for (int i = lo; i < hi; ++i) {
         const int l = min(max(cu_in[i + 1] - cu_in[i], 0), T);
         const int c0 = min(run, Nmax);
@@ -432,12 +435,17 @@ __global__ void __launch_bounds__(256) k_knn_queue(const float* __restrict__ coo
         const size_t pbase = (size_t)(base + i) * k;
         const size_t obase = ((size_t)b * T + i) * k;
         for (int s = 0; s < nmax; ++s) {
+            // all-reduce min over the 16 lanes of the row by DPP rotations within the row (row_ror 8, 4, 2, 1): VALU moves instead of
+            // four dependent trips through the LDS crossbar (ds_bpermute) - the extraction loop is a latency chain
             unsigned long long best = q[0];
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(best, o, 64);
-                best = other < best ? other : best;
-            }
+#define KNN_ROR(n) do {                                                                                                      \
+                const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)best, 0x120 + (n), 0xf, 0xf, false);            \
+                const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(best >> 32), 0x120 + (n), 0xf, 0xf, false);     \
+                const unsigned long long other_ = ((unsigned long long)hi_ << 32) | lo_;                                     \
+                best = other_ < best ? other_ : best;                                                                        \
+            } while (0)
+            KNN_ROR(8); KNN_ROR(4); KNN_ROR(2); KNN_ROR(1);
+#undef KNN_ROR
             if (q[0] == best && best != ~0ull) {     // keys are unique (they carry j): exactly one lane of the group shifts
 #pragma unroll
                 for (int t = 0; t + 1 < NK; ++t) q[t] = q[t + 1];
