@@ -551,6 +551,9 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #endif
     __syncthreads();
 
+#ifdef RN_EXP_SETPRIO      /* experiment: static priority for the second-dispatched half of the workgroup (MI355X guide, two waves per SIMD, item 4) */
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
     const u32x4 perm0e = EDGE1 ? lds_perm[128 + lane] : perm0, perm1e = EDGE1 ? lds_perm[192 + lane] : perm1;   // routing of the edge MLP's Q
     const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
