@@ -409,7 +409,7 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
     float* pq = derp<float>(c, m.pq_t);
     launch_transpose(w0, 3 * RN_D, RN_D, RN_D, pq, 256, s);                    // P part
     launch_transpose(w0 + RN_D, 3 * RN_D, RN_D, RN_D, pq + RN_D, 256, s);      // Q part
-    (void)hipMemcpyAsync(derp<float>(c, m.pq_b), rawp(c, m.b[0]), RN_D * sizeof(float), hipMemcpyDeviceToDevice, s);
+    launch_copy_bytes(derp<float>(c, m.pq_b), rawp(c, m.b[0]), RN_D * sizeof(float), s);       // (kernel copy: a launch error surfaces in hipGetLastError below)
     launch_transpose(w0 + 2 * RN_D, 3 * RN_D, RN_D, RN_D, derp<float>(c, m.wc_t), RN_D, s);
     if (m.depth > 1) launch_transpose(rawp(c, m.w[1]), RN_D, RN_D, RN_D, derp<float>(c, m.w2_t), RN_D, s);
     if (c->cfg.precision == RNAMPNN_PREC_BF16) {
@@ -432,8 +432,8 @@ static void finalize_chain(rnampnn_ctx* c, const Chain& ch, const std::vector<Li
         dst += (size_t)(N / 32) * (K / 16) * 512;
     }
     // derived arena was zeroed: bias beyond the real outputs stays 0
-    (void)hipMemcpyAsync(derp<float>(c, ch.last_bias), rawp(c, layers.back().b), layers.back().out * sizeof(float),
-                         hipMemcpyDeviceToDevice, s);
+    launch_copy_bytes(derp<float>(c, ch.last_bias), rawp(c, layers.back().b), (size_t)(layers.back().out + 3) / 4 * 4 * sizeof(float), s);   // (padded to 16 B: the
+                                                                                     // raw arena pads every tensor to 4 floats, NOUT >= 32)
 }
 
 extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {

@@ -170,20 +170,31 @@ def c3_dir(tmp_path_factory):
 
 
 def test_config3_epochs_on_reference_data_subset(c3_dir):
-    """BASELINE configs[2]: train.py on (a subset of) the reference's data, 1 x MI355X, Adam, lengths 1 ... 2,436 nt
-    with length-bucketed batches, dropout as the reference (0.4): the loss falls from epoch to epoch, validation
-    recovery is reported."""
+    """BASELINE configs[2]: train.py on (a subset of) the reference's data, 1 x MI355X, Adam, lengths 1 ... 2,436 nt with
+    length-bucketed steps, dropout as the reference (0.4), the trainer loop of rnampnn.utils.train (PaddedLoader, no host syncs).
+    The SAME subset, split and dropout seeds through both trainers: the bf16-mixed loss curve (the reference's setting,
+    utils/train.py:109) must track the exact-f32 curve epoch by epoch (measured: max difference 0.0094 over 120 epochs), and the
+    loss must fall clearly (ln 4 = 1.386 at chance, floor 0.744 for the double-softmax loss): with the reference's optimiser
+    (Adam 2e-3, StepLR(15, 0.8): the step size is down to 0.17 x by epoch 120) on 56 real RNAs with dropout 0.4 the epoch-mean
+    TRAIN-mode loss falls 1.3855 -> 1.3402 (bf16-mixed) / 1.3377 (f32) - asserted as >= 0.04; the 64-RNA fixed-batch run of
+    tests/test_round3_gpu.py::test_matched_recovery_on_trained_logits_64_rnas falls 0.13 in 300 steps and reaches recovery 0.56."""
     sys.path.insert(0, os.path.join(REPO, "rna-mpnn_amd"))
     import train as T
-    args = T.parse(["--data", c3_dir, "--epochs", "10", "--batch-size", "8", "--max-len", "4500", "--max-nt", "4096"])
-    out = T.run(args, log=lambda s: print(s))
-    assert out["n_train"] + out["n_val"] == 59
-    ep = out["epochs"]
-    assert all(np.isfinite(e["train_loss"]) for e in ep)
-    # real structures, torch-default init, dropout 0.4, 80 optimiser steps: the double-softmax loss (ln 4 = 1.386 at
-    # chance, floor 0.744) moves slowly but must move down
-    assert ep[-1]["train_loss"] < ep[0]["train_loss"] - 0.004, [e["train_loss"] for e in ep]
-    assert 0.0 <= ep[-1]["val_micro"] <= 1.0 and 0.0 <= ep[-1]["val_macro"] <= 1.0
+    curves = {}
+    for prec in ("bf16", "f32"):
+        torch.manual_seed(0)                                  # same torch-default initial weights for both runs
+        args = T.parse(["--data", c3_dir, "--epochs", "120", "--batch-size", "8", "--max-len", "4500", "--max-nt", "4096",
+                        "--train-precision", prec])
+        out = T.run(args, log=lambda s: None)
+        assert out["n_train"] + out["n_val"] == 59
+        curves[prec] = [e["train_loss"] for e in out["epochs"]]
+        assert all(np.isfinite(curves[prec]))
+        assert 0.0 <= out["epochs"][-1]["val_micro"] <= 1.0 and 0.0 <= out["epochs"][-1]["val_macro"] <= 1.0
+    b, f = np.array(curves["bf16"]), np.array(curves["f32"])
+    print("config 3 subset: epoch losses bf16-mixed", np.round(b[::15], 4).tolist(), "f32", np.round(f[::15], 4).tolist(),
+          f"max |bf16 - f32| {np.abs(b - f).max():.4f}")
+    assert b[-1] < b[0] - 0.04 and f[-1] < f[0] - 0.04, (b[0], b[-1], f[0], f[-1])
+    assert np.abs(b - f).max() < 0.03, np.abs(b - f).max()       # same data order and dropout masks: the curves stay together
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
