@@ -63,6 +63,7 @@ struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     size_t pq_bp;             // derived f32 bias of Linear 0 in the order of that image's P rows
     size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
     size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
+    size_t img16, b2p16;      // the same for the 16-edge-tile fused kernel
 };
 struct MpnnLayer { int gn_scale, gn_shift; Mlp2 msg, edge; };
 
@@ -219,6 +220,8 @@ static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     m.pq_bp = add_der(c, RN_D * sizeof(float));
     m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
     m.b2p = add_der(c, RN_D * sizeof(float));
+    m.img16 = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
+    m.b2p16 = add_der(c, RN_D * sizeof(float));
     return m;
 }
 
@@ -418,6 +421,8 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
         launch_build_pq_image(w0, rawp(c, m.b[0]), one ? 1 : 0, derp<bf16_t>(c, m.pq_img), derp<float>(c, m.pq_bp), s);
         launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, one ? nullptr : rawp(c, m.w[1]), RN_D, one ? nullptr : rawp(c, m.b[1]),
                                is_edge ? 1 : 0, derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
+        if (!one) launch_build_mlp16_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
+                                           derp<bf16_t>(c, m.img16), derp<float>(c, m.b2p16), s);
     }
 }
 
@@ -621,6 +626,7 @@ static MpnnWB wbf(rnampnn_ctx* c, const Mlp2& m) {
     MpnnWB w;
     w.img = derp<bf16_t>(c, m.img);
     w.b2p = derp<float>(c, m.b2p);
+    if (m.depth > 1) { w.img16 = derp<bf16_t>(c, m.img16); w.b2p16 = derp<float>(c, m.b2p16); }
     return w;
 }
 

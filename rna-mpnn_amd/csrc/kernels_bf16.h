@@ -6,7 +6,11 @@
 struct MpnnWB {              // one MLP of a ResMPNN layer, fast-path layouts
     const bf16_t* img;       // MFMA A/B fragment image of (Wc, W2), see build_mlp_image
     const float* b2p;        // bias of Linear 1 in the kernel's output-channel order
+    const bf16_t* img16 = nullptr;   // the same for the 16-edge-tile kernel (build_mlp16_image), depth-2 MLPs only
+    const float* b2p16 = nullptr;
 };
+void launch_build_mlp16_image(const float* wc, int ld_wc, const float* w2, int ld_w2, const float* b2, int is_edge, bf16_t* img, float* b2p,
+                              hipStream_t s);
 
 // weight preparation (run once per load_state_dict)
 void launch_convert_rows_bf16(const float* src, int ld_src, int rows, int cols, int cols_pad, bf16_t* dst, hipStream_t s);

@@ -883,6 +883,254 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #undef RN_FRAG
 }
 
+// ------------------------------------------------------------------------------------------
+// The same fused ResMPNN step on 16-EDGE tiles with v_mfma_f32_16x16x32 (round 3) - an EXPERIMENT, correct (every parity test passes with
+// RNAMPNN_MPNN16=1) and slower than the 32-edge kernel (212 - 232 us per launch against 163 us at C2), kept as the measured answer to "why not
+// four waves per SIMD".  profiles/r03_pmc_sq_k_mpnn16_bf16_experiment.txt: the SIMDs issue 59.2 M vector + 8.8 M matrix + 10.3 M LDS
+// instructions per launch against 44.8 M + 4.9 M + 4.8 M: a 16x16x32 MFMA holds the vector issue for 8 of its 16 cycles (a 32x32x16 for 8 of
+// its 32), every weight fragment is read from LDS per 16 edges instead of per 32, and the per-tile bookkeeping (accumulator init, masks)
+// repeats twice as often.  Issue slots, not occupancy, bound this computation: ~340 K issue cycles per SIMD of the 387 K the launch lasts
+// (88 %) - the 32-edge kernel needs 232 K and uses 77 % of its 300 K.  Why a second kernel was tried: the 32-edge version keeps ~248
+// registers live per wave (e fragments 32, hidden fragments 32, gathered Q rows 32, two 32x32 accumulator tiles 32, weight ring 32), i.e.
+// two waves per SIMD, and its waves spend 40 % of their cycles waiting to issue behind each other's MFMAs and activation arithmetic.  At
+// 16 edges per tile every per-edge quantity halves (e 16, hidden 16, Q 16, tiles 4 + 4): four waves per SIMD, and the matrix / vector work
+// of different waves overlaps by hardware scheduling instead of by a hand-placed interleave.  A wave owns one residue (32 slots) and walks
+// it as two halves, so the mean over the neighbourhood stays in the wave.
+//   Lane (c, g) = (lane & 15, lane >> 4): edge c of the half on the MFMA columns, k-slice g of a 32-deep k-step.
+//   e fragment of k-step s' (channels 32 s' + 8 g .. + 8 of edge c): the SAME bytes as in the 32-edge kernel - HBM layout unchanged -
+//     at 16-byte unit (2 s' + (g >> 1)) * 64 + 32 (g & 1) + 16 half + c of the block.
+//   First Linears, transposed: tile mb (16 hidden channels 16 mb .. + 16) = P row (accumulator INIT from the wave's LDS slot: no injection
+//     MFMA) + 4 MFMAs over e + 1 routing MFMA for the gathered Q row; GELU; the two tiles 2 s'', 2 s'' + 1 packed to f16 are the fragment of
+//     k-step s'' of the second Linear (element j of slice g <-> hidden channel 16 (2 s'' + (j >> 2)) + 4 g + (j & 3): the second Linear's
+//     images are built in that k order).
+//   Edge second Linear, transposed, rows of tile 2 s' + u <-> channels 32 s' + 8 (m >> 2) + 4 u + (m & 3): a lane's 4 accumulators are
+//     elements 4 u .. 4 u + 3 of the e fragment it loaded - residual add and 16-byte store in place.  Absent slots compute on zeros / P and are
+//     stored back as zeros (one select per fragment): the "absent rows stay zero" invariant of the layout holds.
+//   Message second Linear, un-transposed (A = hidden fragments, B = weights): edges on the accumulator rows; rows of absent edges are
+//     zeroed before the activation (GELU(0) = 0), the sum over rows is 4 in-lane FMAs + one cross-slice reduction per residue.
+// LDS: [4 x 32 KiB images: E1 | E2 | M1 | M2][per wave: P_e, P_m, (unused) 3 x 512 B][bias E2 (row order) | bias M2 512 B each][2 routing fragments].
+#define RN16_WAVES 16
+#define RN16_LDS (131072 + RN16_WAVES * 1536 + 1024 + 2048)
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// hidden channel carried by element j of k-slice g in k-step s of a second Linear; row -> channel of the edge MLP's second Linear
+__host__ __device__ __forceinline__ int hid16(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
+__host__ __device__ __forceinline__ int row16_e(int mb, int m) { return 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3); }
+// images of one depth-2 MLP for the 16-edge kernel: [lin 0][mb][s][lane][8] first Linear's e part (bf16), [lin 1][mb][s][lane][8] second
+// Linear (f16; edge MLP: rows in row16_e order; message MLP: B operand, natural columns); b2p: the second bias in that row order
+__global__ void k_build_mlp16_image(const float* __restrict__ wc, int ld_wc, const float* __restrict__ w2, int ld_w2,
+                                    const float* __restrict__ b2, int is_edge, bf16_t* __restrict__ img, float* __restrict__ b2p) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < 2 * 32 * 64 * 8) {
+        const int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
+        const int m = lane & 15, g = lane >> 4, mb = f >> 2, sft = f & 3;
+        if (which == 0) img[id] = f2bf(wc[(size_t)(16 * mb + m) * ld_wc + 32 * sft + 8 * g + j]);
+        else img[id] = __builtin_bit_cast(bf16_t, (_Float16)w2[(size_t)(is_edge ? row16_e(mb, m) : 16 * mb + m) * ld_w2 + hid16(sft, g, j)]);
+    }
+    if (id < 128) b2p[id] = b2[is_edge ? row16_e(id >> 4, id & 15) : id];
+}
+void launch_build_mlp16_image(const float* wc, int ld_wc, const float* w2, int ld_w2, const float* b2, int is_edge, bf16_t* img, float* b2p,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(k_build_mlp16_image, dim3(2 * 32 * 64 * 8 / 256), dim3(256), 0, s, wc, ld_wc, w2, ld_w2, b2, is_edge, img, b2p);
+}
+
+// (a scheduling fence per tile: without it the compiler hoists the LDS weight reads of many tiles and spills 168 registers)
+#define RN16_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool DO_EDGE>
+__global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e, NodeTabs tab,
+        const bf16_t* __restrict__ img_e, const float* __restrict__ b2e, const bf16_t* __restrict__ img_m, const float* __restrict__ b2m,
+        float* __restrict__ agg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = RN16_WAVES;
+    u32x4* img = reinterpret_cast<u32x4*>(smem);                                 // [lin][mb][s][lane]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    float* slot = reinterpret_cast<float*>(smem + 131072) + wave * 384;           // [P_e 128][P_m 128][spare 128]
+    float* lds_b2e = reinterpret_cast<float*>(smem + 131072 + NW * 1536);
+    float* lds_b2m = lds_b2e + 128;
+    u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_b2m + 128);                    // [u 0..1][lane]
+    const int ntot = pk.cu[pk.B];
+    if (DO_EDGE) stage_image_dma<NW * 64>(img, reinterpret_cast<const u32x4*>(img_e), tid);
+    stage_image_dma<NW * 64>(img + 4096, reinterpret_cast<const u32x4*>(img_m), tid);
+    if (tid < 128) lds_b2e[tid] = DO_EDGE ? b2e[tid] : 0.f;
+    else if (tid < 256) lds_b2m[tid - 128] = b2m[tid - 128];
+    else if (tid < 384) {
+        // routing fragment u: row m of a tile with parity u holds channel 16 u + m of its 32-channel k-step; lane (m, gg) element j is k = 8 gg + j
+        const int t = tid - 256, u = t >> 6, ll = t & 63, m = ll & 15, gg = ll >> 4;
+        const int kk = 16 * u + m;
+        u32x4 pv;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            pv[w] = ((kk >> 3) == gg && (kk & 7) == 2 * w ? 0x3F80u : 0u) | ((kk >> 3) == gg && (kk & 7) == 2 * w + 1 ? 0x3F800000u : 0u);
+        lds_perm[t] = pv;
+    }
+    dma_landed();
+    __syncthreads();
+    const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
+    int blk, blk_end, stride;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (ntot + 7) >> 3, x = blockIdx.x & 7;
+        blk_end = min(ntot, (x + 1) * chunk);
+        stride = (gridDim.x >> 3) * NW;
+        blk = x * chunk + (blockIdx.x >> 3) * NW + wave;
+    } else {
+        blk_end = ntot; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
+    }
+    const int zero_row = pk.Nmax;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    if (blk >= blk_end) return;
+    // Unit = (residue, half).  Everything a unit needs from HBM is requested while the previous unit's last phase (message Linear 2) runs:
+    // its e fragments and Q rows reuse the registers that phase no longer reads, the neighbour index one unit earlier still.
+    auto slot_of = [&](int b, int half) { return 16 * half + c; };
+    auto load_j = [&](int b, int half) -> int {
+        const int sl = 16 * half + c;
+        return (b < blk_end && sl < k) ? nbr[(size_t)b * k + sl] : -1;
+    };
+    auto e_ptr = [&](int b, int half) { return reinterpret_cast<u32x4*>(e) + (size_t)b * 512 + 32 * (g & 1) + 16 * half + c; };
+    auto qrow_of = [&](int j) { return j >= 0 ? (j > zero_row ? zero_row : j) : zero_row; };
+    auto stage_p = [&](int b) {       // the residue's P rows -> f32 in the wave's slot (word w <-> channel ch_nat(w >> 5, w & 31); value = hi + lo)
+        const int w0 = 2 * lane, ch0 = ch_nat(w0 >> 5, w0 & 31), ch1 = ch_nat((w0 + 1) >> 5, (w0 + 1) & 31);
+        if (DO_EDGE) {
+            const u32x2 pw = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + w0);
+            slot[ch0] = lo_bf(pw[0]) + hi_bf(pw[0]);
+            slot[ch1] = lo_bf(pw[1]) + hi_bf(pw[1]);
+        }
+        const u32x2 pm = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + w0);
+        slot[128 + ch0] = lo_bf(pm[0]) + hi_bf(pm[0]);
+        slot[128 + ch1] = lo_bf(pm[1]) + hi_bf(pm[1]);
+    };
+    u32x4 ef[4], q[4], hbf[4];
+    int j = load_j(blk, 0);
+    int jn = load_j(blk, 1);
+    {
+        u32x4* ep0 = e_ptr(blk, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ef[s] = ep0[(2 * s + (g >> 1)) * 64];
+        const int qr = qrow_of(j);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>((DO_EDGE ? tab.q_e : tab.q_m) + (size_t)qr * RN_D + 32 * s + 8 * g);
+    }
+    stage_p(blk);
+    float sums[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // this lane's partial of the message sum, channel 16 nb + c
+    int cnt = 0, half = 0;
+    while (true) {
+        const bool valid = j >= 0;
+        const unsigned mask16 = (unsigned)(__ballot(valid) & 0xffffull);          // bit r: edge r of this half exists (lanes g == 0)
+        cnt += __popc(mask16);
+        float vf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = (float)((mask16 >> (4 * g + i)) & 1u);
+        u32x4* ep = e_ptr(blk, half);
+        // the unit after the next one: only its neighbour index is requested here
+        const int nblk = half ? blk + stride : blk, nhalf = half ^ 1;               // next unit
+        const int nnblk = nhalf ? nblk + stride : nblk;                             // the one after it (half = nhalf ^ 1)
+        const int jnn = load_j(nnblk, nhalf ^ 1);
+        if (DO_EDGE) {
+            // ---- edge Linear 1
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                f32x4 T = *reinterpret_cast<const f32x4*>(slot + 16 * mb + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) T = mfma16(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
+                T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
+                const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
+                const f16x4 gv = x * phi4(x);
+                hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
+                hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
+                RN16_FENCE();
+            }
+            // the message MLP's Q rows are requested now (q is free)
+            {
+                const int qr = qrow_of(j);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qr * RN_D + 32 * s + 8 * g);
+            }
+            // ---- edge Linear 2 + residual: tile 2 s + u <-> elements 4 u .. 4 u + 3 of ef[s]
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                f32x4 T = *reinterpret_cast<const f32x4*>(lds_b2e + 16 * mb + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) T = mfma16h(img[((1 * 8 + mb) * 4 + s) * 64 + lane], hbf[s], T);
+                const f16x4 ph = phi4(cvt_h4(T[0], T[1], T[2], T[3]));
+                const int sp = mb >> 1, u = mb & 1;
+                const unsigned o0 = ef[sp][2 * u], o1 = ef[sp][2 * u + 1];
+                ef[sp][2 * u] = pack2(fma_mix_lo(T[0], lo2(ph), lo_bf(o0)), fma_mix_hi(T[1], lo2(ph), hi_bf(o0)));
+                ef[sp][2 * u + 1] = pack2(fma_mix_lo(T[2], hi2(ph), lo_bf(o1)), fma_mix_hi(T[3], hi2(ph), hi_bf(o1)));
+                if (u == 1) {
+                    if (!valid) ef[sp] = u32x4{0u, 0u, 0u, 0u};              // absent slots stay zero rows
+                    ep[(2 * sp + (g >> 1)) * 64] = ef[sp];
+                }
+                RN16_FENCE();
+            }
+        }
+        // ---- message Linear 1
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            f32x4 T = *reinterpret_cast<const f32x4*>(slot + 128 + 16 * mb + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) T = mfma16(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
+            T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
+            const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
+            const f16x4 gv = x * phi4(x);
+            hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
+            hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
+            RN16_FENCE();
+        }
+        // ---- requests of the next unit: ef and q are dead from here on, the slot after this half's last P read when the block changes
+        const bool has_next = nblk < blk_end;
+        if (has_next) {
+            u32x4* epn = e_ptr(nblk, nhalf);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ef[s] = epn[(2 * s + (g >> 1)) * 64];
+            const int qr = qrow_of(jn);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>((DO_EDGE ? tab.q_e : tab.q_m) + (size_t)qr * RN_D + 32 * s + 8 * g);
+            if (half) stage_p(nblk);
+        }
+        RN16_FENCE();
+        // ---- message Linear 2, un-transposed: rows = edges 4 g + i of this half, column = channel 16 nb + c
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const float bv = lds_b2m[16 * nb + c];
+            f32x4 T = {bv, bv, bv, bv};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) T = mfma16h(hbf[s], img[((3 * 8 + nb) * 4 + s) * 64 + lane], T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T[i] *= vf[i];                        // rows of absent edges: GELU(0) = 0
+            const f16x4 ph = phi4(cvt_h4(T[0], T[1], T[2], T[3]));
+            float sacc = sums[nb];
+            sacc = fma_mix_lo(T[0], lo2(ph), sacc);
+            sacc = fma_mix_hi(T[1], lo2(ph), sacc);
+            sacc = fma_mix_lo(T[2], hi2(ph), sacc);
+            sacc = fma_mix_hi(T[3], hi2(ph), sacc);
+            sums[nb] = sacc;
+            RN16_FENCE();
+        }
+        if (half) {
+            // ---- mean over the residue's edges (+ its own h): fold the four k-slices, lanes g == 0 write
+            const float inv = cnt > 0 ? __builtin_amdgcn_rcpf((float)cnt) : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                float t = sums[nb];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (g == 0) {
+                    const size_t o = (size_t)blk * RN_D + 16 * nb + c;
+                    agg[o] = fmaf(t, inv, tab.h_res ? tab.h_res[o] : 0.f);
+                }
+                sums[nb] = 0.f;
+            }
+            cnt = 0;
+        }
+        if (!has_next) break;
+        blk = nblk; half = nhalf;
+        j = jn; jn = jnn;
+    }
+}
+
 static int num_cus() { return rn_num_cus(); }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
@@ -903,6 +1151,22 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     tab.dbg = dbg;
 #endif
     const bool smallk = k <= 16, mo = msg_out != nullptr;
+    // opt-in (RNAMPNN_MPNN16=1, read per call so that a test can switch it): measured SLOWER on C2 (212 - 232 us per launch against 163 us), see the
+    // kernel's header and DESIGN.md section 4
+    const char* ev16 = getenv("RNAMPNN_MPNN16");
+    const int use16 = ev16 ? atoi(ev16) : 0;
+    if (use16 && !smallk && !mo && !edge1 && do_msg && wm.img16 && (!do_edge || we.img16)) {      // 16-edge tiles, four waves per SIMD
+        int g16 = (max_blocks + RN16_WAVES - 1) / RN16_WAVES;
+        if (g16 >= 8) g16 = (g16 + 7) & ~7;
+        if (g16 > num_cus()) g16 = num_cus();
+        if (g16 < 1) g16 = 1;
+        static DevAttr a0, a1;
+        ensure_dyn_lds((const void*)k_mpnn16_bf16<true>, RN16_LDS, a0);
+        ensure_dyn_lds((const void*)k_mpnn16_bf16<false>, RN16_LDS, a1);
+        if (do_edge) hipLaunchKernelGGL(k_mpnn16_bf16<true>, dim3(g16), dim3(RN16_WAVES * 64), RN16_LDS, s, pk, k, nbr, e, tab, we.img16, we.b2p16, wm.img16, wm.b2p16, agg);
+        else hipLaunchKernelGGL(k_mpnn16_bf16<false>, dim3(g16), dim3(RN16_WAVES * 64), RN16_LDS, s, pk, k, nbr, e, tab, we.img16, we.b2p16, wm.img16, wm.b2p16, agg);
+        return;
+    }
 #define RN_LAUNCH(E, M, S, O, E1)                                                                              \
     do {                                                                                                       \
         static DevAttr attr;                                                                                   \

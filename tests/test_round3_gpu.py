@@ -200,3 +200,23 @@ def test_captured_train_step_equals_eager_and_draws_fresh_masks():
     l3 = cap(y, c, m, seed=4242).clone()
     e3 = model.loss_and_grad(y, c, m, seed=4242)
     assert float(l3) == float(e3) and float(l3) != float(l1)
+
+
+def test_sixteen_edge_tile_kernel_experiment_matches_default_kernel(monkeypatch):
+    """The opt-in 16-edge-tile fused ResMPNN kernel (RNAMPNN_MPNN16=1; kept as a measured negative result) computes what the
+    default 32-edge kernel computes: same logits within bf16 rounding of the different summation orders, on a ragged k = 30 batch."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    coords, mask, _ = synth.synth_batch([64, 20, 47, 33, 5, 58], first_index=77)
+    model = RNAMPNN(precision="bf16", num_res_neighbours=30, num_res_mpnn_layers=4, padding_len=64)
+    sd = synth.closed_form_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to("cuda:0").eval()
+    c, m = torch.from_numpy(coords), torch.from_numpy(mask)
+    base = model(c, m).clone()
+    monkeypatch.setenv("RNAMPNN_MPNN16", "1")
+    alt = model(c, m).clone()
+    monkeypatch.delenv("RNAMPNN_MPNN16")
+    assert torch.isfinite(alt).all() and (alt[mask == 0] == 0).all()
+    assert not torch.equal(alt, base)                             # (a different kernel really ran)
+    assert (alt - base).abs().max() < 2e-2, float((alt - base).abs().max())
