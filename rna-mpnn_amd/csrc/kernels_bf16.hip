@@ -126,6 +126,33 @@ __device__ __forceinline__ f16x4 phi4(f16x4 x) {
     f16x4 p = __builtin_elementwise_fma(x, q, h4(0.5f));
     return __builtin_elementwise_min(__builtin_elementwise_max(p, h4(0.f)), h4(1.f));
 }
+// The two edge kernels work in a SCALED activation domain y = a x, a = 1 / sqrt(9.5) (kGA): then min(x^2, 9.5) / 9.5 = clamp01(y^2) and the
+// clamp is a free output modifier of the multiply - one instruction less per pair of activations (8 -> 7; both kernels are bound by the
+// issue of exactly these instructions).  Phi(x) = clamp01(1/2 + y Q(clamp01(y^2))), Q's coefficients = those of q times 9.5^i / a.  The factor
+// is folded into what feeds the first Linears (P / Q tables, W0 and b0 of the embedding, the biases of the second Linears) and the edge
+// tensor itself is stored scaled (e_hat = a e: e_hat' = e_hat + y Phi(y) needs no rescaling); the message mean, the taps and the stage API
+// divide it out.  phi*s take y.
+static constexpr float kGA = 0.324442842f, kGAi = 3.082207001f;
+#define RN_QS0 1.19803158f
+#define RN_QS1 -1.57943700f
+#define RN_QS2 1.33882663f
+#define RN_QS3 -0.45929830f
+__device__ __forceinline__ f16x4 clamp01h(f16x4 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, h4(0.f)), h4(1.f)); }
+__device__ __forceinline__ f16x2 clamp01h(f16x2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, h2(0.f)), h2(1.f)); }
+__device__ __forceinline__ f16x4 phi4s(f16x4 y) {
+    const f16x4 s = clamp01h(y * y);
+    f16x4 q = __builtin_elementwise_fma(s, h4(RN_QS3), h4(RN_QS2));
+    q = __builtin_elementwise_fma(q, s, h4(RN_QS1));
+    q = __builtin_elementwise_fma(q, s, h4(RN_QS0));
+    return clamp01h(__builtin_elementwise_fma(y, q, h4(0.5f)));
+}
+__device__ __forceinline__ f16x2 phi2s(f16x2 y) {
+    const f16x2 s = clamp01h(y * y);
+    f16x2 q = __builtin_elementwise_fma(s, h2(RN_QS3), h2(RN_QS2));
+    q = __builtin_elementwise_fma(q, s, h2(RN_QS1));
+    q = __builtin_elementwise_fma(q, s, h2(RN_QS0));
+    return clamp01h(__builtin_elementwise_fma(y, q, h2(0.5f)));
+}
 __device__ __forceinline__ f16x2 lo2(f16x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f16x2 hi2(f16x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
@@ -252,13 +279,13 @@ __global__ void k_build_mlp_image(const float* __restrict__ wc, int ld_wc, const
         // the second Linear consumes the hidden activations, which the fused kernel keeps in f16: f16 operands
         img[id] = which == 1 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
     }
-    if (id < 128) {
+    if (id < 128) {       // (scaled activation domain: the second Linear's output is a x2 = W2 . (y1 Phi) + a b2)
         if (out_perm) {
             int ob = id >> 5, m = id & 31;                // position 32*ob + 16*h + i  <-> row m
             int h = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
-            b2p[32 * ob + 16 * h + i] = b2[ch_efrag(ob, m)];
+            b2p[32 * ob + 16 * h + i] = kGA * b2[ch_efrag(ob, m)];
         } else {
-            b2p[id] = b2[id];
+            b2p[id] = kGA * b2[id];
         }
     }
 }
@@ -292,7 +319,7 @@ __global__ void k_build_embed_image(const float* __restrict__ w0, const float* _
         int j = id & 7, lane = (id >> 3) & 63, f = id >> 9;
         int mb = f / EMB_KS, s = f % EMB_KS, r = lane & 31, h = lane >> 5;
         int feat = emb_feature_of_slot(h, 8 * s + j);
-        img[id] = feat >= 0 ? f2bf(w0[(size_t)ch_nat(mb, r) * RN_ERAW + feat]) : (bf16_t)0;
+        img[id] = feat >= 0 ? f2bf(kGA * w0[(size_t)ch_nat(mb, r) * RN_ERAW + feat]) : (bf16_t)0;     // (scaled domain: y1 = a (W0 f + b0))
     } else if (id < n0 + n1) {
         int e = id - n0;
         int j = e & 7, lane = (e >> 3) & 63, f = e >> 9;
@@ -302,7 +329,7 @@ __global__ void k_build_embed_image(const float* __restrict__ w0, const float* _
     }
     if (id < 128) {
         int ob = id >> 5, m = id & 31, h = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
-        b1p[32 * ob + 16 * h + i] = b1[ch_efrag(ob, m)];
+        b1p[32 * ob + 16 * h + i] = kGA * b1[ch_efrag(ob, m)];
     }
 }
 void launch_build_embed_image(const float* w0, const float* w1, const float* b1, bf16_t* img, float* b1p, hipStream_t s) {
@@ -324,7 +351,7 @@ __global__ void k_efrag_to_rows(const bf16_t* __restrict__ ef, const int* __rest
         const bf16_t* src = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
         float* dst = rows + row * RN_D + 8 * c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = bf2f(src[j]);
+        for (int j = 0; j < 8; ++j) dst[j] = kGAi * bf2f(src[j]);          // (the tensor is stored as a e)
     }
 }
 // row-major f32 edge rows -> fragment-major bf16.  Every slot of every block is written: padding slots and absent
@@ -346,7 +373,7 @@ __global__ void k_rows_to_efrag(const float* __restrict__ rows, const int* __res
         bf16_t* dst = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
         const float* src = rows + row * RN_D + 8 * c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = real ? f2bf(src[j]) : (bf16_t)0;
+        for (int j = 0; j < 8; ++j) dst[j] = real ? f2bf(kGA * src[j]) : (bf16_t)0;
     }
 }
 static unsigned conv_grid(size_t max_elems) { size_t g = (max_elems + 255) / 256; return (unsigned)(g < 8192 ? (g ? g : 1) : 8192); }
@@ -543,7 +570,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         lds_bwe[tid] = hh == 0 ? ew : 0u;
         if (hh == 0) {
             const float bs = __uint_as_float(mw << 16) + __uint_as_float(mw & 0xffff0000u);
-            lds_gb[32 * blk4 + rr] = bs * (float)phi2(cvt_h2(bs, bs))[0];
+            lds_gb[32 * blk4 + rr] = bs * (float)phi2s(cvt_h2(bs, bs))[0];      // (bs = a b2: wm.b2p is stored scaled)
         }
     }
 #ifdef RN_DMA_STAGE
@@ -660,7 +687,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     // is consumed by the very next instruction); a quarter is 2 granules for the first Linears
     // (A: x, x^2, clamp, first Horner step; B: rest of Phi, x Phi -> hb) and 3 for the second ones (C: the f32 tail -
     // residual add and bf16 repack of e, or the running sum of the mean).  g* = context of the block the chain belongs to.
-    static_assert(RN_PHI_DEG == 4, "the granule form of the epilogue implements the 4-coefficient Phi");
+    static_assert(RN_PHI_DEG == 4, "the granule form of the epilogue implements the 4-coefficient Phi (scaled domain, phi4s)");
     float s0 = 0.f, s1 = 0.f;
     float ghres[4] = {0.f, 0.f, 0.f, 0.f};           // h of the block whose message epilogues are running (channel 32 cb + r)
     f16x4 gx = h4(0.f), gs = h4(0.f), gq = h4(0.f);    // state carried between the granules of a quarter
@@ -681,11 +708,11 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #endif
         if constexpr (ph == 0) {
             gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
-            gs = __builtin_elementwise_min(gx * gx, h4(9.5f));
-            gq = __builtin_elementwise_fma(gs, h4(-0.00017380498f), h4(0.0048129941f));
+            gs = clamp01h(gx * gx);                    // (scaled domain: the clamp is the multiply's output modifier)
+            gq = __builtin_elementwise_fma(gs, h4(RN_QS3), h4(RN_QS2));
         } else if constexpr (ph == 1) {
-            gq = __builtin_elementwise_fma(gq, gs, h4(-0.05394074f));
-            gq = __builtin_elementwise_fma(gq, gs, h4(0.38869277f));
+            gq = __builtin_elementwise_fma(gq, gs, h4(RN_QS1));
+            gq = __builtin_elementwise_fma(gq, gs, h4(RN_QS0));
             const f16x4 pp = __builtin_elementwise_fma(gx, gq, h4(0.5f));
             gq = __builtin_elementwise_min(__builtin_elementwise_max(pp, h4(0.f)), h4(1.f));      // gq now holds Phi
             if constexpr ((kind == 0 && !EDGE1) || kind == 2) {    // hidden activations -> f16 operand fragments of the second Linear
@@ -723,7 +750,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                         const int er = (i & 3) + 8 * (i >> 2) + 4 * h;
                         const int node = gblk * npb + er / k;
                         if (er < npb * k && node < ntot)
-                            msg_out[((size_t)gblk * npb * k + er) * RN_D + 32 * cb + r] = T[i] * (float)((gvmask >> er) & 1u);
+                            msg_out[((size_t)gblk * npb * k + er) * RN_D + 32 * cb + r] = kGAi * T[i] * (float)((gvmask >> er) & 1u);
                     }
                 }
                 for (int q1 = 0; q1 < npb; ++q1) {
@@ -737,7 +764,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                         sum = fmaf(T[i], (float)((segh >> ((i & 3) + 8 * (i >> 2))) & 1u), sum);
                     sum += __shfl_xor(sum, 32, 64);
                     const int cnt = __popc(seg);
-                    if (h == 0) agg[(size_t)node * RN_D + 32 * cb + r] = sum / (float)(cnt > 0 ? cnt : 1) + (tab.h_res ? tab.h_res[(size_t)node * RN_D + 32 * cb + r] : 0.f);
+                    if (h == 0) agg[(size_t)node * RN_D + 32 * cb + r] = kGAi * sum / (float)(cnt > 0 ? cnt : 1) + (tab.h_res ? tab.h_res[(size_t)node * RN_D + 32 * cb + r] : 0.f);
                 }
             }
         }
@@ -801,7 +828,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             const unsigned vmask = (unsigned)(__ballot(j >= 0) & 0xffffffffull);   // bit r = edge r is real
             const int cnt_all = __popc(vmask);
             gblk = blk; gvmask = vmask; gcntf = (float)(32 - cnt_all);
-            ginv = cnt_all > 0 ? __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;
+            ginv = cnt_all > 0 ? kGAi * __builtin_amdgcn_rcpf((float)cnt_all) : 0.f;      // (the summed messages are a m)
             if (DO_MSG && !SMALLK && !MSGOUT) {       // (the wave's slot still holds THIS block's row: the next one is staged behind chain 12)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) ghres[mb] = __uint_as_float(lds_p[256 + 32 * mb + r]);
@@ -931,7 +958,7 @@ __global__ void k_build_mlp16_image(const float* __restrict__ wc, int ld_wc, con
         if (which == 0) img[id] = f2bf(wc[(size_t)(16 * mb + m) * ld_wc + 32 * sft + 8 * g + j]);
         else img[id] = __builtin_bit_cast(bf16_t, (_Float16)w2[(size_t)(is_edge ? row16_e(mb, m) : 16 * mb + m) * ld_w2 + hid16(sft, g, j)]);
     }
-    if (id < 128) b2p[id] = b2[is_edge ? row16_e(id >> 4, id & 15) : id];
+    if (id < 128) b2p[id] = kGA * b2[is_edge ? row16_e(id >> 4, id & 15) : id];      // (scaled activation domain, as the 32-edge kernel)
 }
 void launch_build_mlp16_image(const float* wc, int ld_wc, const float* w2, int ld_w2, const float* b2, int is_edge, bf16_t* img, float* b2p,
                               hipStream_t s) {
@@ -1037,7 +1064,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
                 for (int s = 0; s < 4; ++s) T = mfma16(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
                 T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
                 const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
-                const f16x4 gv = x * phi4(x);
+                const f16x4 gv = x * phi4s(x);
                 hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
                 hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
                 RN16_FENCE();
@@ -1054,7 +1081,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
                 f32x4 T = *reinterpret_cast<const f32x4*>(lds_b2e + 16 * mb + 4 * g);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) T = mfma16h(img[((1 * 8 + mb) * 4 + s) * 64 + lane], hbf[s], T);
-                const f16x4 ph = phi4(cvt_h4(T[0], T[1], T[2], T[3]));
+                const f16x4 ph = phi4s(cvt_h4(T[0], T[1], T[2], T[3]));
                 const int sp = mb >> 1, u = mb & 1;
                 const unsigned o0 = ef[sp][2 * u], o1 = ef[sp][2 * u + 1];
                 ef[sp][2 * u] = pack2(fma_mix_lo(T[0], lo2(ph), lo_bf(o0)), fma_mix_hi(T[1], lo2(ph), hi_bf(o0)));
@@ -1074,7 +1101,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
             for (int s = 0; s < 4; ++s) T = mfma16(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
             T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
             const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
-            const f16x4 gv = x * phi4(x);
+            const f16x4 gv = x * phi4s(x);
             hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
             hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
             RN16_FENCE();
@@ -1100,7 +1127,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
             for (int s = 0; s < 4; ++s) T = mfma16h(hbf[s], img[((3 * 8 + nb) * 4 + s) * 64 + lane], T);
 #pragma unroll
             for (int i = 0; i < 4; ++i) T[i] *= vf[i];                        // rows of absent edges: GELU(0) = 0
-            const f16x4 ph = phi4(cvt_h4(T[0], T[1], T[2], T[3]));
+            const f16x4 ph = phi4s(cvt_h4(T[0], T[1], T[2], T[3]));
             float sacc = sums[nb];
             sacc = fma_mix_lo(T[0], lo2(ph), sacc);
             sacc = fma_mix_hi(T[1], lo2(ph), sacc);
@@ -1111,7 +1138,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
         }
         if (half) {
             // ---- mean over the residue's edges (+ its own h): fold the four k-slices, lanes g == 0 write
-            const float inv = cnt > 0 ? __builtin_amdgcn_rcpf((float)cnt) : 0.f;
+            const float inv = cnt > 0 ? kGAi * __builtin_amdgcn_rcpf((float)cnt) : 0.f;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
                 float t = sums[nb];
@@ -1220,7 +1247,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
     constexpr int NFRAG = 4 * EMB_KS + 32;
     const int tid = threadIdx.x;
     float* lds_b = reinterpret_cast<float*>(smem + (size_t)NFRAG * 1024);      // both bias vectors: a global read per channel block
-    if (tid < 128) lds_b[tid] = b0[tid];                                        // of every edge block would expose an L2 round trip each
+    if (tid < 128) lds_b[tid] = kGA * b0[tid];                                  // of every edge block would expose an L2 round trip each (scaled domain)
     else if (tid < 256) lds_b[tid] = b1p[tid - 128];
     {   // 60 KiB image: loads of a thread first, LDS writes after (see stage_image)
         constexpr int NT = EE_WAVES * 64, PER = (NFRAG * 64 + NT - 1) / NT;
@@ -1320,7 +1347,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
 #pragma unroll
             for (int t = 0; t < 4; ++t) {           // packed-f16 GELU, hidden activations stay f16 (as in the fused kernel)
                 const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-                const f16x4 g = x * phi4(x);
+                const f16x4 g = x * phi4s(x);
                 hb[2 * mb][t] = __builtin_bit_cast(unsigned, lo2(g));
                 hb[2 * mb + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
             }
@@ -1337,7 +1364,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
                 u32x4 nw;
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
-                    const f16x4 ph = phi4(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
+                    const f16x4 ph = phi4s(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
                     nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) & vmask;
                     nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) & vmask;
                 }
@@ -2095,10 +2122,10 @@ __global__ void k_build_pq_image(const float* __restrict__ w0, const float* __re
     if (id >= 8 * 8 * 64 * 8) return;
     int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, ob = f >> 3, ks = f & 7, r = lane & 31, h = lane >> 5;
     int row = (efrag && ob < 4) ? ch_efrag(ob, r) : ch_nat(ob & 3, r), col = (ob < 4 ? 0 : 128) + 16 * ks + 8 * h + j;
-    dst[id] = f2bf(w0[(size_t)row * 384 + col]);
+    dst[id] = f2bf(kGA * w0[(size_t)row * 384 + col]);          // (scaled domain: the tables hold a P and a Q)
     if (id < 128) {
         int ob2 = id >> 5, m = id & 31, hh = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
-        b1p[32 * ob2 + 16 * hh + i] = b1[efrag ? ch_efrag(ob2, m) : ch_nat(ob2, m)];
+        b1p[32 * ob2 + 16 * hh + i] = kGA * b1[efrag ? ch_efrag(ob2, m) : ch_nat(ob2, m)];
     }
 }
 void launch_build_pq_image(const float* w0, const float* b1, int efrag, bf16_t* dst, float* b1p, hipStream_t s) {
