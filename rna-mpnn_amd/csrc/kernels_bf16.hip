@@ -220,6 +220,17 @@ __device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
 #endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// Storage format of the per-edge tensor e of this path (fragment-major, see efrag_ptr): f16 of a e.  |a e| stays far inside the f16 range,
+// the 11 mantissa bits beat bf16's 8, and - the reason - the residual update e <- e + GELU(.) of the fused kernel becomes ONE packed fma on
+// the fragment words as loaded (bf16 storage cost an unpack, an f32 mixed fma and a repack per element: 10 vector instructions per four
+// elements against 2, 128 of the ~1,460 a block issues), and the products e . Wc run as f16 MFMAs on the words as loaded.
+// RN_E_F16=0 builds the bf16-storage form (A/B).
+#ifndef RN_E_F16
+#define RN_E_F16 1
+#endif
+__device__ __forceinline__ bf16_t e_enc(float x) { return RN_E_F16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f2bf(x); }
+__device__ __forceinline__ float e_dec(bf16_t v) { return RN_E_F16 ? (float)__builtin_bit_cast(_Float16, v) : bf2f(v); }
+__device__ __forceinline__ f32x16 mfma_e(u32x4 a, u32x4 b, f32x16 c) { return RN_E_F16 ? mfma32h(a, b, c) : mfma32(a, b, c); }
 
 // channel held by accumulator row m of a 32-row block when the output order is "natural per lane":
 // lane half h = (m>>2)&1, register i = (m&3) + 4*(m>>3)  ->  channel 32*blk + 16*h + i
@@ -259,7 +270,7 @@ __global__ void k_build_mlp_image(const float* __restrict__ wc, int ld_wc, const
         if (id < 2 * 32 * 64 * 8) {
             int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
             int r = lane & 31, h = lane >> 5, mb = f >> 3, s = f & 7;
-            img[id] = which == 0 ? f2bf(wc[(size_t)ch_efrag(mb, r) * ld_wc + 16 * s + 8 * h + j]) : (bf16_t)0;
+            img[id] = which == 0 ? e_enc(wc[(size_t)ch_efrag(mb, r) * ld_wc + 16 * s + 8 * h + j]) : (bf16_t)0;
         }
         if (id < 128) b2p[id] = 0.f;
         return;
@@ -276,8 +287,8 @@ __global__ void k_build_mlp_image(const float* __restrict__ wc, int ld_wc, const
             int row = out_perm ? ch_efrag(ob, r) : 32 * ob + r;
             v = w2[(size_t)row * ld_w2 + 32 * mb + 16 * h + 8 * sp + j];
         }
-        // the second Linear consumes the hidden activations, which the fused kernel keeps in f16: f16 operands
-        img[id] = which == 1 ? __builtin_bit_cast(bf16_t, (_Float16)v) : f2bf(v);
+        // the second Linear consumes the hidden activations, which the fused kernel keeps in f16: f16 operands; the first one consumes e (e_enc)
+        img[id] = which == 1 ? __builtin_bit_cast(bf16_t, (_Float16)v) : e_enc(v);
     }
     if (id < 128) {       // (scaled activation domain: the second Linear's output is a x2 = W2 . (y1 Phi) + a b2)
         if (out_perm) {
@@ -351,7 +362,7 @@ __global__ void k_efrag_to_rows(const bf16_t* __restrict__ ef, const int* __rest
         const bf16_t* src = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
         float* dst = rows + row * RN_D + 8 * c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = kGAi * bf2f(src[j]);          // (the tensor is stored as a e)
+        for (int j = 0; j < 8; ++j) dst[j] = kGAi * e_dec(src[j]);         // (the tensor is stored as a e)
     }
 }
 // row-major f32 edge rows -> fragment-major bf16.  Every slot of every block is written: padding slots and absent
@@ -373,7 +384,7 @@ __global__ void k_rows_to_efrag(const float* __restrict__ rows, const int* __res
         bf16_t* dst = ef + ((size_t)blk * 512 + s * 64 + 32 * h + r) * 8;
         const float* src = rows + row * RN_D + 8 * c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = real ? f2bf(kGA * src[j]) : (bf16_t)0;
+        for (int j = 0; j < 8; ++j) dst[j] = real ? e_enc(kGA * src[j]) : (bf16_t)0;
     }
 }
 static unsigned conv_grid(size_t max_elems) { size_t g = (max_elems + 255) / 256; return (unsigned)(g < 8192 ? (g ? g : 1) : 8192); }
@@ -666,7 +677,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             else T = mfma32(ones_a, u32x4{bwn, 0u, 0u, 0u}, z);
         } else if constexpr (i <= 8) {
             constexpr int s = i - 1;
-            if constexpr (kind == 0 || kind == 2) T = mfma32(wf[s], ef[s], T);
+            if constexpr (kind == 0 || kind == 2) T = mfma_e(wf[s], ef[s], T);
             else if constexpr (kind == 1) T = mfma32h(wf[s], hb[s], T);
             else T = mfma32h(hb[s], wf[s], T);
 #ifndef RN_EXP_NOLDS
@@ -723,8 +734,14 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         } else if constexpr (resid) {                  // e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
             constexpr int sp = v >> 1, t = 2 * (v & 1);
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
+#if RN_E_F16
+            // e is f16 as stored: x Phi + e is one packed fma per word (gx = the quarter's four pre-activations, carried from granule A)
+            ef[2 * cb + sp][t] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(gx), lo2(gq), __builtin_bit_cast(f16x2, o0)));
+            ef[2 * cb + sp][t + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(gx), hi2(gq), __builtin_bit_cast(f16x2, o1)));
+#else
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
             ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
+#endif
 #if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
             if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
 #endif
@@ -955,7 +972,7 @@ __global__ void k_build_mlp16_image(const float* __restrict__ wc, int ld_wc, con
     if (id < 2 * 32 * 64 * 8) {
         const int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
         const int m = lane & 15, g = lane >> 4, mb = f >> 2, sft = f & 3;
-        if (which == 0) img[id] = f2bf(wc[(size_t)(16 * mb + m) * ld_wc + 32 * sft + 8 * g + j]);
+        if (which == 0) img[id] = e_enc(wc[(size_t)(16 * mb + m) * ld_wc + 32 * sft + 8 * g + j]);
         else img[id] = __builtin_bit_cast(bf16_t, (_Float16)w2[(size_t)(is_edge ? row16_e(mb, m) : 16 * mb + m) * ld_w2 + hid16(sft, g, j)]);
     }
     if (id < 128) b2p[id] = kGA * b2[is_edge ? row16_e(id >> 4, id & 15) : id];      // (scaled activation domain, as the 32-edge kernel)
@@ -1061,7 +1078,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
             for (int mb = 0; mb < 8; ++mb) {
                 f32x4 T = *reinterpret_cast<const f32x4*>(slot + 16 * mb + 4 * g);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) T = mfma16(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
+                for (int s = 0; s < 4; ++s) T = RN_E_F16 ? mfma16h(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T) : mfma16(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
                 T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
                 const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
                 const f16x4 gv = x * phi4s(x);
@@ -1081,11 +1098,17 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
                 f32x4 T = *reinterpret_cast<const f32x4*>(lds_b2e + 16 * mb + 4 * g);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) T = mfma16h(img[((1 * 8 + mb) * 4 + s) * 64 + lane], hbf[s], T);
-                const f16x4 ph = phi4s(cvt_h4(T[0], T[1], T[2], T[3]));
+                const f16x4 xq = cvt_h4(T[0], T[1], T[2], T[3]);
+                const f16x4 ph = phi4s(xq);
                 const int sp = mb >> 1, u = mb & 1;
                 const unsigned o0 = ef[sp][2 * u], o1 = ef[sp][2 * u + 1];
+#if RN_E_F16
+                ef[sp][2 * u] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(xq), lo2(ph), __builtin_bit_cast(f16x2, o0)));
+                ef[sp][2 * u + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(xq), hi2(ph), __builtin_bit_cast(f16x2, o1)));
+#else
                 ef[sp][2 * u] = pack2(fma_mix_lo(T[0], lo2(ph), lo_bf(o0)), fma_mix_hi(T[1], lo2(ph), hi_bf(o0)));
                 ef[sp][2 * u + 1] = pack2(fma_mix_lo(T[2], hi2(ph), lo_bf(o1)), fma_mix_hi(T[3], hi2(ph), hi_bf(o1)));
+#endif
                 if (u == 1) {
                     if (!valid) ef[sp] = u32x4{0u, 0u, 0u, 0u};              // absent slots stay zero rows
                     ep[(2 * sp + (g >> 1)) * 64] = ef[sp];
@@ -1098,7 +1121,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
         for (int mb = 0; mb < 8; ++mb) {
             f32x4 T = *reinterpret_cast<const f32x4*>(slot + 128 + 16 * mb + 4 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) T = mfma16(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
+            for (int s = 0; s < 4; ++s) T = RN_E_F16 ? mfma16h(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T) : mfma16(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
             T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
             const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
             const f16x4 gv = x * phi4s(x);
@@ -1364,9 +1387,16 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
                 u32x4 nw;
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
+#if RN_E_F16
+                    const f16x4 xq = cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]);
+                    const f16x4 gq4 = xq * phi4s(xq);
+                    nw[t] = __builtin_bit_cast(unsigned, lo2(gq4)) & vmask;
+                    nw[t + 1] = __builtin_bit_cast(unsigned, hi2(gq4)) & vmask;
+#else
                     const f16x4 ph = phi4s(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
                     nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) & vmask;
                     nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) & vmask;
+#endif
                 }
                 ewp[64 * (2 * ob + sp)] = nw;
             }
@@ -1841,6 +1871,13 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
     }
 }
 
+#ifdef NU_STAMPS      // diagnostic build only: per-phase clock of workgroups 0 / 100 / 239 (never shipped enabled)
+__device__ unsigned long long nu_dbg[3][8];
+#define NU_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 239)) \
+    nu_dbg[blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NU_STAMP(i) do { } while (0)
+#endif
 struct PqJob { const bf16_t* img; const float* bias; float* p; bf16_t* q; };   // img: [8 ob][8 ks][64][8]; ob<4 -> P rows (stored as split-bf16 words), >=4 -> Q rows
 
 template <int NJOBS>
@@ -1855,6 +1892,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     const int row = row_blk + 32 * wave + r;
     const bool ok = row < ntot;
     const int rr = ok ? row : 0;
+    NU_STAMP(0);
     const float* cf = coef + (size_t)pk.node_b[rr] * 256;
     // the HBM loads of the rows go out first; the weight images (L2-resident) are staged into LDS while they fly
     f32x4 vx[8][2], va[8][2];
@@ -1895,6 +1933,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
         }
     }
+    NU_STAMP(1);
     u32x4 xf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -1914,7 +1953,9 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = vx[s][1];
         }
     }
+    NU_STAMP(2);
     __syncthreads();
+    NU_STAMP(3);
 #pragma unroll
     for (int jb = 0; jb < NJOBS; ++jb) {
         const PqJob& jbq = jb == 0 ? j0 : j1;
@@ -1947,6 +1988,9 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    NU_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NU_STAMP(5);
 }
 
 // The same update with ONE workgroup per RNA (n <= 256): GraphNorm statistics (two-pass), normalisation and the projections in one launch -
@@ -2150,12 +2194,27 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     }
     if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     dim3 grid((pk.Nmax + 127) / 128);
+    // Measured and NOT kept (round 3, C2, 21.9 us per launch for this form): (a) four workgroups per 128-row block (one per job and P / Q half,
+    // 32 KiB of LDS, four per CU): 28.3 us; (b) every global access coalesced through a per-wave LDS tile (1 KiB row loads, 128-byte-line
+    // P / Q stores): 26.2 us.  Phase stamps (NU_STAMPS) explain both: the launch moves 16 MB in and 63 MB out (h' f32, two P tables of
+    // (hi, lo) words, two Q tables) - the load phase ends when the LAST row of the chip-wide 16 MB burst has arrived, the MFMA + store phase
+    // runs at the rate the 63 MB drain; neither the access shape nor the occupancy is what bounds them.
     static DevAttr attr1, attr2;
     ensure_dyn_lds((const void*)k_node_update<1>, 65536 + 1024, attr1);
     ensure_dyn_lds((const void*)k_node_update<2>, 131072 + 1024, attr2);
     const float* cf = scale ? coef : nullptr;
     if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536 + 1024, s, pk, x, add, cf, h_out, j0, j1);
     else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072 + 1024, s, pk, x, add, cf, h_out, j0, j1);
+#ifdef NU_STAMPS
+    {
+        unsigned long long hst[3][8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(nu_dbg), sizeof(hst));
+        for (int w = 0; w < 3; ++w)
+            fprintf(stderr, "[node update stamps wg %d] start +%llu | rows+coef %llu | pack+hout %llu | barrier %llu | mfma+stores %llu | drain %llu | total %llu\n", w,
+                    hst[w][0] - hst[0][0], hst[w][1] - hst[w][0], hst[w][2] - hst[w][1], hst[w][3] - hst[w][2], hst[w][4] - hst[w][3], hst[w][5] - hst[w][4], hst[w][5] - hst[w][0]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -38,6 +38,9 @@ __device__ __forceinline__ float drop_mul(const TDrop& d, unsigned site, unsigne
 // both elements of pair P (element indices 2P, 2P + 1) when P is known to fit 32 bits (every [rows][D] tensor of the trainer: the
 // entry points bound rows * D / 2 < 2^32); key = drop_key(d, site)
 __device__ __forceinline__ void drop_pair(const TDrop& d, unsigned key, unsigned P, float& m0, float& m1) {
+#ifdef TE_EXP_NOHASH      // timing experiment only (wrong masks): what the hash costs
+    m0 = m1 = __uint_as_float((P + key) & 0x3f800000u); return;
+#endif
     if (d.thresh == 0u) { m0 = 1.f; m1 = 1.f; return; }
     const unsigned x = drop_hash(P + key);
     m0 = (x & 0xffffu) >= d.thresh ? d.scale : 0.f;
@@ -52,11 +55,17 @@ __device__ __forceinline__ void drop8(const TDrop& d, unsigned key, unsigned P8,
 // coefficients minimax-fitted to the erf form (max |x Phi - gelu| 2.7e-4, below the bf16 rounding of the operands these
 // values are converted to); derivative = Phi + x phi.  The f32 kernels (parity grade) keep erff.
 __device__ __forceinline__ float phi_fast(float x) {
+#ifdef TE_EXP_NOACT       // timing experiment only (wrong values): what the transcendental GELU costs
+    return fmaf(x, 0.25f, 0.5f);
+#endif
     const float p = fmaf(x * x, -0.10012571f, -2.3087657f);           // -log2(e) (c0 + c1 x^2)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
 }
 __device__ __forceinline__ float gelu_fast(float x) { return x * phi_fast(x); }
 __device__ __forceinline__ float gelu_d_fast(float x) {
+#ifdef TE_EXP_NOACT
+    return fmaf(x, 0.5f, 0.5f);
+#endif
     return fmaf(x * 0.3989422804f, __builtin_amdgcn_exp2f(x * x * -0.72134752f), phi_fast(x));
 }
 
@@ -1999,6 +2008,9 @@ void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int 
 // feeds the transposed reads of the weight-gradient MFMAs and, as row-major fragments, the MFMAs of d pre1 (output transposed in the
 // accumulators as in k_emm128: lane = row, 16-byte stores).  W2's fragment image is staged through the LDS region that then holds g'.
 __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d) {          // (gelu_fast(x), gelu_d_fast(x)) sharing the sigmoid
+#ifdef TE_EXP_NOACT
+    g = x * fmaf(x, 0.25f, 0.5f); d = fmaf(x, 0.5f, 0.5f); return;
+#endif
     const float p = fmaf(x * x, -0.10012571f, -2.3087657f);
     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
     g = x * sg;
