@@ -706,7 +706,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         constexpr int c = decltype(cc)::value, g = decltype(gg)::value;
         constexpr int kind = c >> 2, cb = c & 3;
         constexpr bool resid = kind == 1 || (EDGE1 && kind == 0);     // this chain's output is added to e
-        constexpr int gpq = ((kind & 1) || resid) ? 3 : 2;            // granules per quarter
+        constexpr int gpq = (kind == 3 || (resid && !RN_E_F16)) ? 3 : 2;   // granules per quarter (f16 e: the residual add is two instructions of granule B)
         constexpr int v = g / gpq, ph = g % gpq;
 #ifdef RN_EXP_NOGELU
         if constexpr (ph == 0) { gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]); gq = gx; }
@@ -731,17 +731,22 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                 hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
                 hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
             }
-        } else if constexpr (resid) {                  // e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
+#if RN_E_F16
+            if constexpr (resid) {                     // e <- e + GELU(.): e is f16 as stored, x Phi + e is one packed fma per fragment word
+                constexpr int sp = v >> 1, t = 2 * (v & 1);
+                const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
+                ef[2 * cb + sp][t] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(gx), lo2(gq), __builtin_bit_cast(f16x2, o0)));
+                ef[2 * cb + sp][t + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(gx), hi2(gq), __builtin_bit_cast(f16x2, o1)));
+#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
+                if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
+#endif
+            }
+#endif
+        } else if constexpr (resid) {                  // (bf16 storage) e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
             constexpr int sp = v >> 1, t = 2 * (v & 1);
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
-#if RN_E_F16
-            // e is f16 as stored: x Phi + e is one packed fma per word (gx = the quarter's four pre-activations, carried from granule A)
-            ef[2 * cb + sp][t] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(gx), lo2(gq), __builtin_bit_cast(f16x2, o0)));
-            ef[2 * cb + sp][t + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(gx), hi2(gq), __builtin_bit_cast(f16x2, o1)));
-#else
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
             ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
-#endif
 #if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
             if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
 #endif
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             }
         }
     };
-#define RN_NGRAN(c) (((((c) >> 2) & 1) || (EDGE1 && (c) < 4)) ? 12 : 8)
+#define RN_NGRAN(c) ((((c) >> 2) == 3 || (!RN_E_F16 && (((c) >> 2) == 1 || (EDGE1 && (c) < 4)))) ? 12 : 8)
 
     // ---- prologue: state of the first block, fragments of its first chain
     j = (slot_ok && blk * npb + q0 < ntot) ? jraw_first : -1;
