@@ -102,6 +102,8 @@ void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, co
 // `from` (optional): d pre2 is formed on the fly while the tile is staged - mode 1: dY = d e_out, d pre2 = valid ? dY gelu'(pre2) mask(site2) : 0
 // (the edge update's residual backward); mode 2: d pre2 = valid ? dagg[row / k] inv_cnt[row / k] gelu'(pre2) mask(site2) : 0 (the message mean's)
 struct EBwd2Src { int mode; const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; };
+void te_gemm_bwd1x2(const TRows& rows, const tb16* dY1, const tb16* dY2, const tb16* X, tb16* DE, const float* W1, const float* W2, int ldw,
+                    float* dW1, float* dW2, int ldw_out, const TScratch& sc, hipStream_t s);
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
                   const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from = nullptr);
 void te_inv_count(const PackInfo& pk, int k, const int* nbr, float* inv_cnt, hipStream_t s);   // 1 / max(#valid slots, 1) per residue

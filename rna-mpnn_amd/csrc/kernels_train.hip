@@ -2312,6 +2312,124 @@ void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, co
     hipLaunchKernelGGL(k_emm_bwd1, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, X, DE, W, ldw, wimg_lookup(W, ldw, false, 1), sc.p, mk, rps);
     reduce_parts(sc.p, splits, mk, (int)mk, 128, dW, ldw_out, s, tmp);
 }
+// ---- the first-Linear backward of the TWO per-edge MLPs of a layer that share their input e (edge update and message MLP, mpnn.py:212-262) in one
+// pass: dW1 += dY1^T e, dW2 += dY2^T e, dE += dY1 . W1 + dY2 . W2.  As two k_emm_bwd1 launches e and dE are read twice and dE is written twice
+// (8 [E][128] passes); here once each (5).  One 8-wave workgroup per CU (two waves per SIMD): three 64-row LDS tiles + both weight images
+// (32 KiB each, fragments read per use - two register-resident slices would not leave room for the four accumulator tiles of a wave).
+// Weight-gradient share of a wave: output rows 32 (wave >> 1), columns 64 (wave & 1) of both products; dE share: rows 32 (wave >> 2) of the
+// tile, channel block wave & 3.  Same accumulation order per output element as the two-launch form over a split: results differ from it only
+// through the split boundaries (partials are per split) - compared against it in tests/test_round3_gpu.py.
+__global__ void __launch_bounds__(512, 1) k_emm_bwd1x2(TRows rows, const tb16* __restrict__ dY1, const tb16* __restrict__ dY2,
+        const tb16* __restrict__ Xin, tb16* __restrict__ DE, const float* __restrict__ W1, const float* __restrict__ W2, int ldw,
+        const unsigned short* __restrict__ wimg1, const unsigned short* __restrict__ wimg2, float* __restrict__ part, size_t pstride,
+        int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned short tA1[64 * TN_PITCH], tA2[64 * TN_PITCH], tB[64 * TN_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short img1[32 * 64 * 8], img2[32 * 64 * 8];
+    const int R = nrows(rows);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;                  // weight-gradient share
+    const int rh = wave >> 2, cbw = wave & 3;                 // dE share
+    const int p_begin = blockIdx.z * rows_per_split, p_end = min(R, p_begin + rows_per_split);
+    const int ch = tid & 15, rg = tid >> 4;                   // 16-byte chunk ch of rows rg, rg + 32
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    if (tid < 256) stage_wimage(img1, wimg1, W1, ldw, false, 1, tid);
+    else stage_wimage(img2, wimg2, W2, ldw, false, 1, tid - 256);
+    auto load_tile = [&](int m0, tu32x4 (&x1)[2], tu32x4 (&x2)[2], tu32x4 (&xb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + rg + 32 * i;
+            const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+            x1[i] = *reinterpret_cast<const tu32x4*>(dY1 + (size_t)mc * 128 + 8 * ch);
+            x2[i] = *reinterpret_cast<const tu32x4*>(dY2 + (size_t)mc * 128 + 8 * ch);
+            xb[i] = *reinterpret_cast<const tu32x4*>(Xin + (size_t)mc * 128 + 8 * ch);
+        }
+    };
+    tf32x16 acc1[2], acc2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc1[b][i] = 0.f; acc2[b][i] = 0.f; }
+    const tu32x4* w1 = reinterpret_cast<const tu32x4*>(img1) + cbw * 64 + lane;
+    const tu32x4* w2 = reinterpret_cast<const tu32x4*>(img2) + cbw * 64 + lane;
+    tu32x4 a1[2], a2[2], b0[2];
+    int m0 = p_begin;
+    if (m0 < p_end) load_tile(m0, a1, a2, b0);
+    while (m0 < p_end) {
+        __syncthreads();                                      // the previous tile's fragment reads (first time: the image writes) are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = m0 + rg + 32 * i < p_end;
+            *reinterpret_cast<tu32x4*>(tA1 + (rg + 32 * i) * TN_PITCH + 8 * ch) = ok ? a1[i] : z4;
+            *reinterpret_cast<tu32x4*>(tA2 + (rg + 32 * i) * TN_PITCH + 8 * ch) = ok ? a2[i] : z4;
+            *reinterpret_cast<tu32x4*>(tB + (rg + 32 * i) * TN_PITCH + 8 * ch) = ok ? b0[i] : z4;
+        }
+        __syncthreads();
+        load_tile(m0 + 64, a1, a2, b0);
+        const int m = m0 + 32 * rh + r;
+        const int mc = m < p_end ? m : (R > 0 ? R - 1 : 0);
+        tu32x4 old[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) old[g] = *reinterpret_cast<const tu32x4*>(DE + (size_t)mc * 128 + 32 * cbw + 16 * g + 8 * h);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const tu32x4 af1 = tr_frag(tA1, 16 * ks, 32 * wr, lane), af2 = tr_frag(tA2, 16 * ks, 32 * wr, lane);
+            tu32x4 bf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(tB, 16 * ks, 64 * wc + 32 * b, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { acc1[b] = tmfma(af1, bf[b], acc1[b]); acc2[b] = tmfma(af2, bf[b], acc2[b]); }
+        }
+        {
+            const unsigned short* x1 = tA1 + (32 * rh + r) * TN_PITCH + 8 * h;
+            const unsigned short* x2 = tA2 + (32 * rh + r) * TN_PITCH + 8 * h;
+            tf32x16 dn;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dn[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                dn = tmfma(w1[ks * 4 * 64], *reinterpret_cast<const tu32x4*>(x1 + 16 * ks), dn);
+                dn = tmfma(w2[ks * 4 * 64], *reinterpret_cast<const tu32x4*>(x2 + 16 * ks), dn);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float ov[8], o[8];
+                unpack8(old[g], ov);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o[q] = dn[8 * g + q] + ov[q];
+                if (m < p_end) *reinterpret_cast<tu32x4*>(DE + (size_t)m * 128 + 32 * cbw + 16 * g + 8 * h) = tpack8(o);
+            }
+        }
+        m0 += 64;
+    }
+    float* d1 = part + (size_t)blockIdx.z * pstride;
+    float* d2 = d1 + 128 * 128;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = 64 * wc + 32 * b + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const size_t o = (size_t)(32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col;
+            d1[o] = acc1[b][i]; d2[o] = acc2[b][i];
+        }
+    }
+}
+// dW1[128][ldw_out] += dY1^T X, dW2 += dY2^T X, DE += dY1 . W1 + dY2 . W2      (W1, W2 [128 out][ldw]: the Wc blocks of the two first Linears)
+void te_gemm_bwd1x2(const TRows& rows, const tb16* dY1, const tb16* dY2, const tb16* X, tb16* DE, const float* W1, const float* W2, int ldw,
+                    float* dW1, float* dW2, int ldw_out, const TScratch& sc, hipStream_t s) {
+    const size_t mk = 128 * 128, pstride = 2 * mk;
+    long long cap = (long long)((sc.floats - (size_t)800 * 128) / pstride) - 16;
+    int splits = (rows.maxrows + 1023) / 1024;               // >= 16 tiles per workgroup
+    const int want = rn_num_cus();                           // one 8-wave workgroup per CU (127 KiB of LDS)
+    if (splits > want) splits = want;
+    if (splits > cap) splits = (int)cap;
+    if (splits < 1) splits = 1;
+    const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
+    float* tmp = sc.p + (size_t)splits * pstride;
+    hipLaunchKernelGGL(k_emm_bwd1x2, dim3(1, 1, splits), dim3(512), 0, s, rows, dY1, dY2, X, DE, W1, W2, ldw, wimg_lookup(W1, ldw, false, 1),
+                       wimg_lookup(W2, ldw, false, 1), sc.p, pstride, rps);
+    reduce_parts(sc.p, splits, pstride, (int)mk, 128, dW1, ldw_out, s, tmp);
+    reduce_parts(sc.p + mk, splits, pstride, (int)mk, 128, dW2, ldw_out, s, tmp);
+}
 // dW[128][ldw_out] += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask        (W [128 out][ldw] as nn.Linear stores it)
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
                   const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from) {

@@ -220,3 +220,30 @@ def test_sixteen_edge_tile_kernel_experiment_matches_default_kernel(monkeypatch)
     assert torch.isfinite(alt).all() and (alt[mask == 0] == 0).all()
     assert not torch.equal(alt, base)                             # (a different kernel really ran)
     assert (alt - base).abs().max() < 2e-2, float((alt - base).abs().max())
+
+
+def test_paired_first_linear_backward_matches_the_two_launch_form(monkeypatch):
+    """bf16-mixed backward: the e-side pass (dWc, dE) of the edge-update MLP and the message MLP of a layer runs as ONE kernel
+    (k_emm_bwd1x2: e and dE read once); RNAMPNN_NO_BWD1_PAIR=1 runs the two k_emm_bwd1 launches it replaces.  Same loss (the forward is
+    untouched); gradients equal up to the bf16 rounding of dE (one rounding per layer instead of two) and the f32 summation order of the
+    per-split partials."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    coords, mask, labels = synth.synth_batch([64, 20, 47, 33, 5, 58, 61, 40], first_index=31)
+    torch.manual_seed(3)
+    model = RNAMPNN(precision="bf16", num_res_neighbours=30, num_res_mpnn_layers=4, padding_len=64).to("cuda:0").train()
+    c, m, y = (torch.from_numpy(a) for a in (coords, mask, labels))
+    l_pair = float(model.loss_and_grad(y, c, m, seed=77)); g_pair = model.flat_grad.clone()
+    monkeypatch.setenv("RNAMPNN_NO_BWD1_PAIR", "1")
+    l_two = float(model.loss_and_grad(y, c, m, seed=77)); g_two = model.flat_grad.clone()
+    monkeypatch.delenv("RNAMPNN_NO_BWD1_PAIR")
+    assert l_pair == l_two
+    assert torch.isfinite(g_pair).all() and not torch.equal(g_pair, g_two)       # (a different kernel really ran)
+    cos = float(torch.nn.functional.cosine_similarity(g_pair, g_two, dim=0))
+    rel = float((g_pair - g_two).norm() / g_two.norm())
+    assert cos > 0.9999 and rel < 1e-2, (cos, rel)
+    # per parameter tensor: nothing is missing or misplaced (the two weight gradients of the pair land in their own Wc blocks)
+    for prm, off in model._grad_slices:
+        a, b = g_pair[off: off + prm.numel()], g_two[off: off + prm.numel()]
+        if float(b.norm()) > 1e-8:
+            assert float((a - b).norm() / b.norm()) < 5e-2, (off, float((a - b).norm() / b.norm()))
