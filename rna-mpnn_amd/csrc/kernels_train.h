@@ -58,8 +58,9 @@ void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* s
 void t_edge_pq_bwd(const PackInfo& pk, int k, const float* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
               float* dshift, const TScratch& sc, hipStream_t s);
-int  t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, const TDrop& dr, unsigned site, hipStream_t s);
-int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat,
+// stat [N][heads][3]: the forward writes (row max, normaliser) per (query, head); the backward reads them and adds delta (it is a TAPE: one per attention layer)
+int  t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, float* stat, const TDrop& dr, unsigned site, hipStream_t s);
+int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const float* dO, int heads, float* dqkv, float* stat,
                      const TDrop& dr, unsigned site, hipStream_t s);
 // loss = mean_valid CE(softmax(logits), label) and d loss / d logits (packed rows)
 void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlogits_p, hipStream_t s);

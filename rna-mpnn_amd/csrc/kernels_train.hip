@@ -555,7 +555,7 @@ __device__ __forceinline__ unsigned long long att_idx(int qrow, int heads, int h
 }
 template <int HD>
 __global__ void __launch_bounds__(64) k_attn_fwd_t(PackInfo pk, const float* __restrict__ qkv, int heads, float* __restrict__ out,
-                                                   TDrop dr, unsigned site) {
+                                                   float* __restrict__ stat, TDrop dr, unsigned site) {
     const int b = blockIdx.x, hd = blockIdx.y;
     const int n = pk.len[b];
     const int qi = blockIdx.z * 64 + threadIdx.x;
@@ -588,21 +588,27 @@ __global__ void __launch_bounds__(64) k_attn_fwd_t(PackInfo pk, const float* __r
         float* op = out + (size_t)qrow * RN_D + hd * HD;
 #pragma unroll
         for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+        if (stat) {                                  // softmax statistics of the row for the backward (tape: one key pass there instead of three)
+            float* st = stat + ((size_t)qrow * heads + hd) * 3;
+            st[0] = m; st[1] = l;
+        }
     }
 }
-int t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, const TDrop& dr, unsigned site, hipStream_t s) {
+int t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, float* stat, const TDrop& dr, unsigned site, hipStream_t s) {
     dim3 grid(pk.B, heads, (pk.T + 63) / 64);
     const int hd = RN_D / heads;
-#define RN_ATT(H) if (hd == H) { hipLaunchKernelGGL(k_attn_fwd_t<H>, grid, dim3(64), 0, s, pk, qkv, heads, out, dr, site); return 0; }
+#define RN_ATT(H) if (hd == H) { hipLaunchKernelGGL(k_attn_fwd_t<H>, grid, dim3(64), 0, s, pk, qkv, heads, out, stat, dr, site); return 0; }
     RN_ATT(16) RN_ATT(32) RN_ATT(8) RN_ATT(64)
 #undef RN_ATT
     return 1;
 }
 
-// backward.  pass 1 (thread per query): row max m, normaliser l, delta = sum_j P_ij dP_ij with dP_ij = M_ij (dO_i . v_j), dq_i
-//            pass 2 (thread per key):   dv_j = sum_i P_ij M_ij dO_i,  dk_j = scale * sum_i dS_ij q_i,  dS = P (dP - delta)
+// backward.  The forward taped the row max m and the normaliser l of every (query, head) (stat[0..1]); delta_i = sum_j P_ij dP_ij with
+//            dP_ij = M_ij (dO_i . v_j) equals dO_i . O_i (O = the forward output, dropout included), so no pass over the keys is needed for it.
+//            pass 1 (thread per query): dq_i = scale * sum_j dS_ij k_j, dS = P (dP - delta); stat[2] = delta    (ONE pass over the keys; it was three)
+//            pass 2 (thread per key):   dv_j = sum_i P_ij M_ij dO_i,  dk_j = scale * sum_i dS_ij q_i
 template <int HD>
-__global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
+__global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ O, const float* __restrict__ dO,
         float* __restrict__ dqkv, float* __restrict__ stat, int heads, TDrop dr, unsigned site) {
     const int b = blockIdx.x, hd = blockIdx.y;
     const int n = pk.len[b];
@@ -614,34 +620,21 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __r
     const float scale = rsqrtf((float)HD);
     const float* row = qkv + (size_t)qrow * 384 + hd * HD;
     float q[HD], g[HD], dq[HD];
+    float delta = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { q[d] = row[d] * scale; g[d] = dO[(size_t)qrow * RN_D + hd * HD + d]; dq[d] = 0.f; }
-    float m = -3.0e38f;
-    for (int j = 0; j < n; ++j) {
-        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
-        float sc = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kj[d], sc);
-        m = fmaxf(m, sc);
+    for (int d = 0; d < HD; ++d) {
+        q[d] = row[d] * scale; g[d] = dO[(size_t)qrow * RN_D + hd * HD + d]; dq[d] = 0.f;
+        delta = fmaf(g[d], O[(size_t)qrow * RN_D + hd * HD + d], delta);
     }
-    float l = 0.f, delta = 0.f;
+    float* st = stat + ((size_t)qrow * heads + hd) * 3;
+    const float m = st[0], linv = 1.0f / st[1];
     for (int j = 0; j < n; ++j) {
         const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
         const float* vj = kj + 128;
         float sc = 0.f, dp = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
-        const float pj = __expf(sc - m);
-        l += pj; delta = fmaf(pj, dp * drop_mul(dr, site, att_idx(qrow, heads, hd, j)), delta);
-    }
-    delta /= l;
-    for (int j = 0; j < n; ++j) {
-        const float* kj = qkv + (size_t)(base + j) * 384 + 128 + hd * HD;
-        const float* vj = kj + 128;
-        float sc = 0.f, dp = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { sc = fmaf(q[d], kj[d], sc); dp = fmaf(g[d], vj[d], dp); }
-        const float ds = __expf(sc - m) / l * (dp * drop_mul(dr, site, att_idx(qrow, heads, hd, j)) - delta);
+        const float ds = __expf(sc - m) * linv * (dp * drop_mul(dr, site, att_idx(qrow, heads, hd, j)) - delta);
 #pragma unroll
         for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, kj[d], dq[d]);
     }
@@ -649,8 +642,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q(PackInfo pk, const float* __r
         float* o = dqkv + (size_t)(base + qi) * 384 + hd * HD;
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = dq[d] * scale;
-        float* st = stat + ((size_t)(base + qi) * heads + hd) * 3;
-        st[0] = m; st[1] = l; st[2] = delta;
+        st[2] = delta;
     }
 }
 template <int HD>
@@ -688,12 +680,12 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv(PackInfo pk, const float* __
         for (int d = 0; d < HD; ++d) { o[d] = dk[d]; o[128 + d] = dv[d]; }
     }
 }
-int t_attention_bwd(const PackInfo& pk, const float* qkv, const float* dO, int heads, float* dqkv, float* stat,
+int t_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const float* dO, int heads, float* dqkv, float* stat,
                     const TDrop& dr, unsigned site, hipStream_t s) {
     dim3 grid(pk.B, heads, (pk.T + 63) / 64);
     const int hd = RN_D / heads;
 #define RN_ATT(H) \
-    if (hd == H) { hipLaunchKernelGGL(k_attn_bwd_q<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads, dr, site); \
+    if (hd == H) { hipLaunchKernelGGL(k_attn_bwd_q<H>, grid, dim3(64), 0, s, pk, qkv, O, dO, dqkv, stat, heads, dr, site); \
                    hipLaunchKernelGGL(k_attn_bwd_kv<H>, grid, dim3(64), 0, s, pk, qkv, dO, dqkv, stat, heads, dr, site); return 0; }
     RN_ATT(16) RN_ATT(32) RN_ATT(8) RN_ATT(64)
 #undef RN_ATT
