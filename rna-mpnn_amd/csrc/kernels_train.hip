@@ -538,10 +538,89 @@ __global__ void __launch_bounds__(256) k_gn_bwd(PackInfo pk, const float* __rest
         part[(size_t)b * 256 + 128 + c] = Sg0;
     }
 }
+// ---- the same backward for LONG RNAs (T > GN_SPLIT_T): with one workgroup per (RNA, 32-channel chunk) a batch of a few 4,000-nt RNAs runs on 28 of
+// the 256 CUs (231 us per call on the config-3 epoch).  Here the rows of an RNA are cut into `nsplit` ranges (grid.z): pass A accumulates the four
+// sums of a range around a per-(RNA, channel) PIVOT (the RNA's first row: sum (x - p), sum (x - p)^2, sum g, sum g (x - p) - the shifted one-pass
+// form, whose cancellation is relative to |mean - p| ~ sigma, not to |mean|), pass B folds the ranges in fixed order, forms the same
+// quantities as k_gn_bwd and writes dx for its range.  Deterministic; x and dy are read twice instead of three / two times.
+#define GN_SPLIT_T 512
+#define GN_SPLIT_ROWS 256
+__global__ void __launch_bounds__(256) k_gn_bwd_sums(PackInfo pk, const float* __restrict__ x, const float* __restrict__ dy, int nsplit,
+                                                     float* __restrict__ sums) {          // sums [B][nsplit][4][128]
+    __shared__ float red[4][8][32];
+    const int b = blockIdx.x, z = blockIdx.z;
+    const int n = pk.len[b];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    const int r0 = z * GN_SPLIT_ROWS, r1 = min(n, r0 + GN_SPLIT_ROWS);
+    float s1 = 0.f, s2 = 0.f, sg = 0.f, sgx = 0.f;
+    if (r0 < n) {
+        const size_t base = (size_t)pk.cu[b] * RN_D;
+        const float* xb = x + base;
+        const float* gb = dy + base;
+        const float pv = xb[c];
+        for (int r = r0 + rg; r < r1; r += 8) {
+            const float d = xb[(size_t)r * RN_D + c] - pv, g = gb[(size_t)r * RN_D + c];
+            s1 += d; s2 = fmaf(d, d, s2); sg += g; sgx = fmaf(g, d, sgx);
+        }
+    }
+    red[0][rg][cl] = s1; red[1][rg][cl] = s2; red[2][rg][cl] = sg; red[3][rg][cl] = sgx;
+    __syncthreads();
+    if (rg < 4) {
+        float t = 0.f;
+        for (int g = 0; g < 8; ++g) t += red[rg][g][cl];
+        sums[(((size_t)b * nsplit + z) * 4 + rg) * 128 + c] = t;
+    }
+}
+__global__ void __launch_bounds__(256) k_gn_bwd_apply(PackInfo pk, const float* __restrict__ x, const float* __restrict__ dy,
+        const float* __restrict__ scale, int t_tot, int nsplit, const float* __restrict__ sums, float* __restrict__ dx, float* __restrict__ part) {
+    const int b = blockIdx.x, z = blockIdx.z;
+    const int n = pk.len[b];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, c = blockIdx.y * 32 + cl;
+    if (n <= 0) { if (rg == 0 && z == 0) { part[(size_t)b * 256 + c] = 0.f; part[(size_t)b * 256 + 128 + c] = 0.f; } return; }
+    const int r0 = z * GN_SPLIT_ROWS, r1 = min(n, r0 + GN_SPLIT_ROWS);
+    if (r0 >= n) return;
+    float S1 = 0.f, S2 = 0.f, Sg0 = 0.f, Sgp = 0.f;
+    const int used = (n + GN_SPLIT_ROWS - 1) / GN_SPLIT_ROWS;
+    for (int q = 0; q < used; ++q) {                            // fixed order: every workgroup of the RNA forms the same totals
+        const float* sp = sums + ((size_t)b * nsplit + q) * 4 * 128 + c;
+        S1 += sp[0]; S2 += sp[128]; Sg0 += sp[256]; Sgp += sp[384];
+    }
+    const size_t base = (size_t)pk.cu[b] * RN_D;
+    const float* xb = x + base;
+    const float* gb = dy + base;
+    const float fn = (float)n, cpad = (float)(t_tot - n);
+    const float pv = xb[c];
+    const float dm = S1 / fn, mean = pv + dm;                   // mean - pivot, mean
+    const float Ss = S2 - fn * dm * dm;                         // sum (x - mean)^2
+    const float Sgx0 = Sgp - dm * Sg0;                          // sum g (x - mean)
+    const float var = (Ss + cpad * mean * mean) / fn + kSEPS;
+    const float sd = sqrtf(var), sc = scale[c];
+    const float Sg = Sg0 * sc, Sgx = Sgx0 * sc;
+    const float dvar = -0.5f * Sgx / (var * sd);
+    const float dmu = -Sg / sd + dvar * 2.f * cpad * mean / fn;
+    float* db = dx + base;
+    for (int r = r0 + rg; r < r1; r += 8) {
+        const float d = xb[(size_t)r * RN_D + c] - mean;
+        db[(size_t)r * RN_D + c] = gb[(size_t)r * RN_D + c] * sc / sd + dvar * 2.f * d / fn + dmu / fn;
+    }
+    if (rg == 0 && z == 0) {
+        part[(size_t)b * 256 + c] = Sgx0 / sd;
+        part[(size_t)b * 256 + 128 + c] = Sg0;
+    }
+}
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
               float* dshift, const TScratch& sc, hipStream_t s) {
     // per-RNA partials of (dscale, dshift), added in RNA order (needs B * 256 floats of scratch)
-    hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B, 4), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, sc.p);
+    const int nsplit = (pk.T + GN_SPLIT_ROWS - 1) / GN_SPLIT_ROWS;
+    const size_t need = (size_t)pk.B * 256 + (size_t)pk.B * nsplit * 512;
+    const char* nosplit = getenv("RNAMPNN_GN_NOSPLIT");          // A/B switch (read per call)
+    if (pk.T > GN_SPLIT_T && need <= sc.floats && !(nosplit && nosplit[0] == '1')) {
+        float* sums = sc.p + (size_t)pk.B * 256;
+        hipLaunchKernelGGL(k_gn_bwd_sums, dim3(pk.B, 4, nsplit), dim3(256), 0, s, pk, x, dy, nsplit, sums);
+        hipLaunchKernelGGL(k_gn_bwd_apply, dim3(pk.B, 4, nsplit), dim3(256), 0, s, pk, x, dy, scale, t_tot, nsplit, sums, dx, sc.p);
+    } else {
+        hipLaunchKernelGGL(k_gn_bwd, dim3(pk.B, 4), dim3(256), 0, s, pk, x, dy, scale, t_tot, dx, sc.p);
+    }
     if (dscale) reduce_parts(sc.p, pk.B, 256, 128, 128, dscale, 128, s);
     if (dshift) reduce_parts(sc.p + 128, pk.B, 256, 128, 128, dshift, 128, s);
 }

@@ -345,7 +345,7 @@ def test_long_rna_and_large_batch_shapes():
     assert torch.isfinite(l2).all() and (l2 - r2).abs().max() < BF16_LOGIT_TOL
 
 
-@pytest.mark.parametrize("cfg", ["default_small", "alt_attn"])
+@pytest.mark.parametrize("cfg", ["default_small", "alt_attn", "alt_attn_long"])
 def test_loss_and_gradients_match_oracle_autograd(cfg):
     """Training path: loss and the gradient of every parameter vs torch autograd through the CPU oracle
     (same double-softmax loss, rnampnn.py:151-154).  f32, dropout off."""
@@ -361,6 +361,9 @@ def test_loss_and_gradients_match_oracle_autograd(cfg):
                   post_fusion_ffn_dim=64, num_post_fusion_ffn_layers=1, num_raw_ffn_layers=1, num_raw_ffn_dim=64,
                   readout_hidden_dim=64, num_readout_layers=1, padding_len=24)
     lens = [14, 5, 9]
+    if cfg == "alt_attn_long":      # RNAs past 512 nt: the row-split GraphNorm backward (k_gn_bwd_sums / _apply) and the taped attention statistics at length
+        hp = dict(hp, padding_len=640)
+        lens = [600, 37, 290]
     coords, mask, labels = synth.synth_batch(lens, first_index=40)
     model, sd_np = _model(hp, state_dict_shapes(hp), "f32")
     onehot = torch.nn.functional.one_hot(torch.from_numpy(labels), 4).float()
