@@ -62,6 +62,10 @@ void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* 
 int  t_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, float* stat, const TDrop& dr, unsigned site, hipStream_t s);
 int  t_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const float* dO, int heads, float* dqkv, float* stat,
                      const TDrop& dr, unsigned site, hipStream_t s);
+// the same on MFMA for the bf16-mixed trainer (head dim 16): returns 1 (nothing launched) when the shape is not covered
+int  te_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, float* stat, const TDrop& dr, unsigned site, hipStream_t s);
+int  te_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const float* dO, int heads, float* dqkv, float* stat,
+                      const TDrop& dr, unsigned site, hipStream_t s);
 // loss = mean_valid CE(softmax(logits), label) and d loss / d logits (packed rows)
 void t_pack_dlogits(const PackInfo& pk, const float* dlogits_padded, float* dlogits_p, hipStream_t s);
 void t_loss_grad(const PackInfo& pk, const float* logits, const int32_t* labels, float* dlogits, float* loss, const TScratch& sc,

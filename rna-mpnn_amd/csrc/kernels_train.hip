@@ -2531,6 +2531,307 @@ void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, 
     reduce_parts(sc.p, splits, pstride, (int)pstride, 128, dW, ldw_out, s, tmp, (int)mk, dbias);
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16-mixed training attention on MFMA (head dim 16; the f32 kernels above stay the parity-grade path).  The thread-per-query f32
+// kernels run at the FMA rate of the vector units (~50 TFLOP/s): on the config-3 epoch - RNAs of up to 4,417 nt, work ~ T^2 - the three of
+// them were 28 % of the kernel time.  Same transposed scheme as the inference kernel (kernels_bf16.hip: k_attention_bf16_hd16):
+//   forward   S^T[key][query] = K . Q^T (one query per lane, the 32 keys of a block on the accumulator registers), online softmax in
+//             lane, dropout mask on the probabilities (the hash of drop_mul / att_idx, one hash per pair of adjacent keys), the masked P
+//             tile is the B operand of O^T[d][query] += V^T . P; the row max and normaliser go to the tape (stat[0..1]).
+//   dQ        per 32-key block: S^T and dP^T[key][query] = V . dO^T by one MFMA each, dS = P (dP M - delta) with delta = dO . O,
+//             dQ^T[d][query] += K^T . dS (the K^T image is staged like the forward's V^T image).
+//   dK, dV    the same with the roles swapped (one KEY per lane, 32 queries of a block on the registers; row statistics of the queries
+//             from LDS): dV^T[d][key] += dO^T . (P M), dK^T[d][key] += Q^T . dS.
+// Q is pre-scaled by 1/4 before its bf16 rounding in all three, so the recomputed S equals the forward's bit for bit and exp(S - m) <= 1.
+// K / V / Q / dO tiles are staged in LDS per chunk of 32-row blocks as ready fragments; any RNA length runs through the same kernels.
+__device__ __forceinline__ float att_mask(const TDrop& d, unsigned hb, int key) {        // == drop_mul(d, site, att_idx(q, heads, hd, key)); hb = hash base of (q, head)
+    if (d.thresh == 0u) return 1.f;
+    const unsigned x = drop_hash(hb + ((unsigned)key >> 1));
+    return ((key & 1) ? x >> 16 : x & 0xffffu) >= d.thresh ? d.scale : 0.f;
+}
+__device__ __forceinline__ unsigned att_hash_base(const TDrop& d, unsigned key_site, int qrow, int heads, int hd) {
+    const unsigned long long P = ((unsigned long long)((unsigned)qrow * (unsigned)heads + (unsigned)hd)) << 12;     // att_idx(...) >> 1 with key = 0 (low 12 bits free)
+    return (unsigned)P + (unsigned)(P >> 32) * 0xC2B2AE35u + key_site;
+}
+// rows [row0, row0 + 32 nb) of qkv column block `col` (+ 16 hd) -> [row][2 halves] A-fragment image (8 bf16 each), scaled; rows >= n are zero
+__device__ __forceinline__ void att_stage_rows(tu32x4* img, const float* __restrict__ src, int ld, int base, int row0, int nb, int n, float scl, int tid, int nthr) {
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int idx = tid; idx < nb * 64; idx += nthr) {
+        const int row = row0 + (idx >> 1), hh = idx & 1;
+        const float* p = src + (size_t)(base + (row < n ? row : n - 1)) * ld + 8 * hh;
+        const tf32x4 a = *reinterpret_cast<const tf32x4*>(p), c = *reinterpret_cast<const tf32x4*>(p + 4);
+        const tu32x4 v = {tpack2(scl * a[0], scl * a[1]), tpack2(scl * a[2], scl * a[3]), tpack2(scl * c[0], scl * c[1]), tpack2(scl * c[2], scl * c[3])};
+        img[idx] = row < n ? v : z4;
+    }
+}
+// the same rows TRANSPOSED: [block][s][h][d 0..15] = 8 rows in the order the packed accumulator registers carry them (A operand of X^T . tile)
+__device__ __forceinline__ void att_stage_rows_t(tu32x4* img, const float* __restrict__ src, int ld, int base, int row0, int nb, int n, float scl, int tid, int nthr) {
+    for (int idx = tid; idx < nb * 64; idx += nthr) {
+        const int d = idx & 15, hh = (idx >> 4) & 1, sblk = (idx >> 5) & 1, blk = idx >> 6;
+        float vals[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + 32 * blk + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+            vals[j] = src[(size_t)(base + (row < n ? row : n - 1)) * ld + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + 32 * blk + 16 * sblk + 8 * (j >> 2) + 4 * hh + (j & 3);
+            vals[j] = row < n ? scl * vals[j] : 0.f;
+        }
+        img[idx] = tu32x4{tpack2(vals[0], vals[1]), tpack2(vals[2], vals[3]), tpack2(vals[4], vals[5]), tpack2(vals[6], vals[7])};
+    }
+}
+#define ATT_CHUNK 32            // 32-row blocks per LDS chunk
+__global__ void __launch_bounds__(512) k_attn_fwd_m16(PackInfo pk, const float* __restrict__ qkv, int heads, float* __restrict__ out,
+                                                      float* __restrict__ stat, TDrop dr, unsigned site) {
+    __shared__ __attribute__((aligned(16))) tu32x4 Kimg[ATT_CHUNK * 64], Vt[ATT_CHUNK * 64];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int qbase = blockIdx.z * 256;
+    if (n <= 0 || qbase >= n) return;
+    const int base = pk.cu[b];
+    const int nkb = (n + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    const int q0 = qbase + 32 * wave;
+    const bool wave_live = q0 < n;
+    const int qi = q0 + r;
+    const int qrow = base + (qi < n ? qi : n - 1);
+    tu32x4 qf = z4;
+    if (qi < n) {
+        const float* qp = qkv + (size_t)qrow * 384 + hd * 16 + 8 * h;
+        const tf32x4 a = *reinterpret_cast<const tf32x4*>(qp), c = *reinterpret_cast<const tf32x4*>(qp + 4);
+        qf = tu32x4{tpack2(0.25f * a[0], 0.25f * a[1]), tpack2(0.25f * a[2], 0.25f * a[3]), tpack2(0.25f * c[0], 0.25f * c[1]), tpack2(0.25f * c[2], 0.25f * c[3])};
+    }
+    const unsigned hb = att_hash_base(dr, drop_key(dr, site), qrow, heads, hd);
+    tf32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float m_run = -3.0e38f, l_run = 0.f;
+    for (int kb0 = 0; kb0 < nkb; kb0 += ATT_CHUNK) {
+        const int cb = min(ATT_CHUNK, nkb - kb0);
+        if (kb0 > 0) __syncthreads();
+        att_stage_rows(Kimg, qkv + 128 + hd * 16, 384, base, 32 * kb0, cb, n, 1.f, tid, 512);
+        att_stage_rows_t(Vt, qkv + 256 + hd * 16, 384, base, 32 * kb0, cb, n, 1.f, tid, 512);
+        __syncthreads();
+        if (!wave_live) continue;
+        for (int kl = 0; kl < cb; ++kl) {
+            const int kb = kb0 + kl;
+            tf32x16 sc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+            sc = tmfma(Kimg[(32 * kl + r) * 2 + h], qf, sc);                      // S^T[key][query]
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                sc[i] = key < n ? sc[i] : -3.0e38f;
+                mx = fmaxf(mx, sc[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float corr = __expf(m_run - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = __expf(sc[i] - m_new); ps += sc[i]; }
+            l_run = l_run * corr + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= corr;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] *= att_mask(dr, hb, 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h);       // (adjacent registers = adjacent keys: the compiler shares the pair's hash)
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const tu32x4 pf = {tpack2(sc[8 * sblk], sc[8 * sblk + 1]), tpack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                   tpack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), tpack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                const tu32x4 vf = r < 16 ? Vt[((kl * 2 + sblk) * 2 + h) * 16 + r] : z4;
+                acc = tmfma(vf, pf, acc);                                       // O^T[d][query]
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qi < n) {
+        const float inv = 1.0f / l_tot;
+        float* op = out + (size_t)qrow * RN_D + hd * 16 + 4 * h;                // rows d = (i&3) + 8(i>>2) + 4h, i < 8
+        *reinterpret_cast<tf32x4*>(op) = tf32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+        *reinterpret_cast<tf32x4*>(op + 8) = tf32x4{acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+        if (h == 0) { float* st = stat + ((size_t)qrow * heads + hd) * 3; st[0] = m_run; st[1] = l_tot; }
+    }
+}
+__global__ void __launch_bounds__(512) k_attn_bwd_q_m16(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ O,
+        const float* __restrict__ dO, float* __restrict__ dqkv, float* __restrict__ stat, int heads, TDrop dr, unsigned site) {
+    __shared__ __attribute__((aligned(16))) tu32x4 Kimg[ATT_CHUNK * 64], Vimg[ATT_CHUNK * 64], Kt[ATT_CHUNK * 64];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int qbase = blockIdx.z * 256;
+    if (n <= 0 || qbase >= n) return;
+    const int base = pk.cu[b];
+    const int nkb = (n + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    const int q0 = qbase + 32 * wave;
+    const bool wave_live = q0 < n;
+    const int qi = q0 + r;
+    const int qrow = base + (qi < n ? qi : n - 1);
+    tu32x4 qf = z4, gf = z4;
+    float delta = 0.f;
+    if (qi < n) {
+        const float* qp = qkv + (size_t)qrow * 384 + hd * 16 + 8 * h;
+        const tf32x4 a = *reinterpret_cast<const tf32x4*>(qp), c = *reinterpret_cast<const tf32x4*>(qp + 4);
+        qf = tu32x4{tpack2(0.25f * a[0], 0.25f * a[1]), tpack2(0.25f * a[2], 0.25f * a[3]), tpack2(0.25f * c[0], 0.25f * c[1]), tpack2(0.25f * c[2], 0.25f * c[3])};
+        const float* gp = dO + (size_t)qrow * RN_D + hd * 16 + 8 * h;
+        const float* op = O + (size_t)qrow * RN_D + hd * 16 + 8 * h;
+        const tf32x4 g0 = *reinterpret_cast<const tf32x4*>(gp), g1 = *reinterpret_cast<const tf32x4*>(gp + 4);
+        const tf32x4 o0 = *reinterpret_cast<const tf32x4*>(op), o1 = *reinterpret_cast<const tf32x4*>(op + 4);
+        gf = tu32x4{tpack2(g0[0], g0[1]), tpack2(g0[2], g0[3]), tpack2(g1[0], g1[1]), tpack2(g1[2], g1[3])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) delta = fmaf(g0[d], o0[d], fmaf(g1[d], o1[d], delta));
+    }
+    delta += __shfl_xor(delta, 32, 64);                          // the two lane halves hold the two halves of d
+    const float* stp = stat + ((size_t)qrow * heads + hd) * 3;
+    const float m = stp[0], linv = 1.0f / stp[1];
+    const unsigned hb = att_hash_base(dr, drop_key(dr, site), qrow, heads, hd);
+    tf32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int kb0 = 0; kb0 < nkb; kb0 += ATT_CHUNK) {
+        const int cb = min(ATT_CHUNK, nkb - kb0);
+        if (kb0 > 0) __syncthreads();
+        att_stage_rows(Kimg, qkv + 128 + hd * 16, 384, base, 32 * kb0, cb, n, 1.f, tid, 512);
+        att_stage_rows(Vimg, qkv + 256 + hd * 16, 384, base, 32 * kb0, cb, n, 1.f, tid, 512);
+        att_stage_rows_t(Kt, qkv + 128 + hd * 16, 384, base, 32 * kb0, cb, n, 1.f, tid, 512);
+        __syncthreads();
+        if (!wave_live) continue;
+        for (int kl = 0; kl < cb; ++kl) {
+            const int kb = kb0 + kl;
+            tf32x16 sc, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+            sc = tmfma(Kimg[(32 * kl + r) * 2 + h], qf, sc);                      // S^T[key][query]
+            dp = tmfma(Vimg[(32 * kl + r) * 2 + h], gf, dp);                      // dP^T[key][query] = v_key . dO_query
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float p = __expf(sc[i] - m) * linv;
+                const float ds = p * (dp[i] * att_mask(dr, hb, key) - delta);
+                sc[i] = key < n ? ds : 0.f;
+            }
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const tu32x4 df = {tpack2(sc[8 * sblk], sc[8 * sblk + 1]), tpack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                   tpack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), tpack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                const tu32x4 kf = r < 16 ? Kt[((kl * 2 + sblk) * 2 + h) * 16 + r] : z4;
+                acc = tmfma(kf, df, acc);                                       // dQ^T[d][query]
+            }
+        }
+    }
+    if (qi < n) {
+        float* o = dqkv + (size_t)qrow * 384 + hd * 16 + 4 * h;
+        *reinterpret_cast<tf32x4*>(o) = tf32x4{0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2], 0.25f * acc[3]};
+        *reinterpret_cast<tf32x4*>(o + 8) = tf32x4{0.25f * acc[4], 0.25f * acc[5], 0.25f * acc[6], 0.25f * acc[7]};
+        if (h == 0) stat[((size_t)qrow * heads + hd) * 3 + 2] = delta;
+    }
+}
+__global__ void __launch_bounds__(512) k_attn_bwd_kv_m16(PackInfo pk, const float* __restrict__ qkv, const float* __restrict__ dO,
+        float* __restrict__ dqkv, const float* __restrict__ stat, int heads, TDrop dr, unsigned site) {
+    __shared__ __attribute__((aligned(16))) tu32x4 Qimg[ATT_CHUNK * 64], Gimg[ATT_CHUNK * 64], Qt[ATT_CHUNK * 64], Gt[ATT_CHUNK * 64];
+    __shared__ float s_m[ATT_CHUNK * 32], s_li[ATT_CHUNK * 32], s_de[ATT_CHUNK * 32];
+    __shared__ unsigned s_hb[ATT_CHUNK * 32];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int n = pk.len[b];
+    const int kbase = blockIdx.z * 256;
+    if (n <= 0 || kbase >= n) return;
+    const int base = pk.cu[b];
+    const int nqb = (n + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const tu32x4 z4 = {0u, 0u, 0u, 0u};
+    const int k0 = kbase + 32 * wave;
+    const bool wave_live = k0 < n;
+    const int kj = k0 + r;
+    const int krow = base + (kj < n ? kj : n - 1);
+    tu32x4 kf = z4, vf = z4;
+    if (kj < n) {
+        const float* kp = qkv + (size_t)krow * 384 + 128 + hd * 16 + 8 * h;
+        const tf32x4 a = *reinterpret_cast<const tf32x4*>(kp), c = *reinterpret_cast<const tf32x4*>(kp + 4);
+        const tf32x4 v0 = *reinterpret_cast<const tf32x4*>(kp + 128), v1 = *reinterpret_cast<const tf32x4*>(kp + 132);
+        kf = tu32x4{tpack2(a[0], a[1]), tpack2(a[2], a[3]), tpack2(c[0], c[1]), tpack2(c[2], c[3])};
+        vf = tu32x4{tpack2(v0[0], v0[1]), tpack2(v0[2], v0[3]), tpack2(v1[0], v1[1]), tpack2(v1[2], v1[3])};
+    }
+    const unsigned key_site = drop_key(dr, site);
+    tf32x16 dk, dv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+    for (int qb0 = 0; qb0 < nqb; qb0 += ATT_CHUNK) {
+        const int cb = min(ATT_CHUNK, nqb - qb0);
+        if (qb0 > 0) __syncthreads();
+        att_stage_rows(Qimg, qkv + hd * 16, 384, base, 32 * qb0, cb, n, 0.25f, tid, 512);
+        att_stage_rows(Gimg, dO + hd * 16, RN_D, base, 32 * qb0, cb, n, 1.f, tid, 512);
+        att_stage_rows_t(Qt, qkv + hd * 16, 384, base, 32 * qb0, cb, n, 0.25f, tid, 512);
+        att_stage_rows_t(Gt, dO + hd * 16, RN_D, base, 32 * qb0, cb, n, 1.f, tid, 512);
+        for (int idx = tid; idx < cb * 32; idx += 512) {
+            const int q = 32 * qb0 + idx;
+            const int qr = base + (q < n ? q : n - 1);
+            const float* st = stat + ((size_t)qr * heads + hd) * 3;
+            s_m[idx] = st[0]; s_li[idx] = 1.0f / st[1]; s_de[idx] = st[2];
+            s_hb[idx] = att_hash_base(dr, key_site, qr, heads, hd);
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        for (int ql = 0; ql < cb; ++ql) {
+            const int qb = qb0 + ql;
+            tf32x16 sc, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+            sc = tmfma(Qimg[(32 * ql + r) * 2 + h], kf, sc);                      // S[query][key], one key per lane
+            dp = tmfma(Gimg[(32 * ql + r) * 2 + h], vf, dp);                      // dP[query][key] = dO_query . v_key
+            tf32x16 pm;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ql_i = (i & 3) + 8 * (i >> 2) + 4 * h, q = 32 * qb + ql_i;
+                const int si = 32 * ql + ql_i;
+                const float p = __expf(sc[i] - s_m[si]) * s_li[si];
+                const float mk = att_mask(dr, s_hb[si], kj);
+                const bool ok = q < n;
+                pm[i] = ok ? p * mk : 0.f;
+                sc[i] = ok ? p * (dp[i] * mk - s_de[si]) : 0.f;
+            }
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const tu32x4 pf = {tpack2(pm[8 * sblk], pm[8 * sblk + 1]), tpack2(pm[8 * sblk + 2], pm[8 * sblk + 3]),
+                                   tpack2(pm[8 * sblk + 4], pm[8 * sblk + 5]), tpack2(pm[8 * sblk + 6], pm[8 * sblk + 7])};
+                const tu32x4 df = {tpack2(sc[8 * sblk], sc[8 * sblk + 1]), tpack2(sc[8 * sblk + 2], sc[8 * sblk + 3]),
+                                   tpack2(sc[8 * sblk + 4], sc[8 * sblk + 5]), tpack2(sc[8 * sblk + 6], sc[8 * sblk + 7])};
+                const tu32x4 gt = r < 16 ? Gt[((ql * 2 + sblk) * 2 + h) * 16 + r] : z4;
+                const tu32x4 qt = r < 16 ? Qt[((ql * 2 + sblk) * 2 + h) * 16 + r] : z4;
+                dv = tmfma(gt, pf, dv);                                         // dV^T[d][key] += dO^T . (P M)
+                dk = tmfma(qt, df, dk);                                         // dK^T[d][key] += (Q / 4)^T . dS
+            }
+        }
+    }
+    if (kj < n) {
+        float* o = dqkv + (size_t)krow * 384 + 128 + hd * 16 + 4 * h;
+        *reinterpret_cast<tf32x4*>(o) = tf32x4{dk[0], dk[1], dk[2], dk[3]};
+        *reinterpret_cast<tf32x4*>(o + 8) = tf32x4{dk[4], dk[5], dk[6], dk[7]};
+        *reinterpret_cast<tf32x4*>(o + 128) = tf32x4{dv[0], dv[1], dv[2], dv[3]};
+        *reinterpret_cast<tf32x4*>(o + 136) = tf32x4{dv[4], dv[5], dv[6], dv[7]};
+    }
+}
+// returns 0 when handled (head dim 16); the caller falls back to the f32 kernels otherwise
+int te_attention_fwd(const PackInfo& pk, const float* qkv, int heads, float* out, float* stat, const TDrop& dr, unsigned site, hipStream_t s) {
+    if (RN_D / heads != 16 || pk.T > 8192 || !stat) return 1;
+    hipLaunchKernelGGL(k_attn_fwd_m16, dim3(pk.B, heads, (pk.T + 255) / 256), dim3(512), 0, s, pk, qkv, heads, out, stat, dr, site);
+    return 0;
+}
+int te_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const float* dO, int heads, float* dqkv, float* stat,
+                     const TDrop& dr, unsigned site, hipStream_t s) {
+    if (RN_D / heads != 16 || pk.T > 8192) return 1;
+    const dim3 grid(pk.B, heads, (pk.T + 255) / 256);
+    hipLaunchKernelGGL(k_attn_bwd_q_m16, grid, dim3(512), 0, s, pk, qkv, O, dO, dqkv, stat, heads, dr, site);
+    hipLaunchKernelGGL(k_attn_bwd_kv_m16, grid, dim3(512), 0, s, pk, qkv, dO, dqkv, stat, heads, dr, site);
+    return 0;
+}
+
 // ---- row kernels on bf16 edge tensors: one thread = two adjacent channels (a 32-bit load), 64 threads per edge row
 // One wave per residue, lane = two adjacent channels.  The k validity flags are taken in ONE load + ballot (a per-slot `if (nbr >= 0)` in the
 // loop is a dependent load -> branch -> load chain per slot: 83 % of the wave cycles were waits), the row loads are unconditional and go

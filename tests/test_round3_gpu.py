@@ -247,3 +247,29 @@ def test_paired_first_linear_backward_matches_the_two_launch_form(monkeypatch):
         a, b = g_pair[off: off + prm.numel()], g_two[off: off + prm.numel()]
         if float(b.norm()) > 1e-8:
             assert float((a - b).norm() / b.norm()) < 5e-2, (off, float((a - b).norm() / b.norm()))
+
+
+@pytest.mark.parametrize("lens,pad", [([64, 20, 47, 33, 5, 58], 64), ([1100, 290, 37], 1120)])
+def test_mfma_training_attention_tracks_the_f32_kernels(monkeypatch, lens, pad):
+    """bf16-mixed trainer: attention forward / backward on MFMA (k_attn_fwd_m16, k_attn_bwd_q_m16, k_attn_bwd_kv_m16) against the f32
+    thread-per-query kernels (RNAMPNN_F32_ATTN=1) with the SAME dropout masks (dropout 0.4 on the attention probabilities too): loss and
+    gradients agree to the bf16 rounding of Q, K, V, P and dS.  The second case crosses the 1,024-key LDS chunk of the kernels."""
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    coords, mask, labels = synth.synth_batch(lens, first_index=91)
+    torch.manual_seed(9)
+    model = RNAMPNN(precision="bf16", num_res_neighbours=6, num_res_mpnn_layers=1, num_embedding_attn_layers=1, padding_len=pad).to("cuda:0").train()
+    c, m, y = (torch.from_numpy(a) for a in (coords, mask, labels))
+    l_m = float(model.loss_and_grad(y, c, m, seed=5)); g_m = model.flat_grad.clone()
+    monkeypatch.setenv("RNAMPNN_F32_ATTN", "1")
+    l_f = float(model.loss_and_grad(y, c, m, seed=5)); g_f = model.flat_grad.clone()
+    monkeypatch.delenv("RNAMPNN_F32_ATTN")
+    assert np.isfinite(l_m) and abs(l_m - l_f) < 2e-3, (l_m, l_f)
+    assert torch.isfinite(g_m).all() and not torch.equal(g_m, g_f)               # (different kernels really ran)
+    cos = float(torch.nn.functional.cosine_similarity(g_m, g_f, dim=0))
+    assert cos > 0.995, cos
+    for prm, off in model._grad_slices:                                            # no parameter's gradient is missing or misplaced
+        a, b = g_m[off: off + prm.numel()], g_f[off: off + prm.numel()]
+        if float(b.norm()) > 1e-6:
+            pc = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+            assert pc > 0.97, (off, pc)
