@@ -865,11 +865,76 @@ __global__ void __launch_bounds__(256) k_graph_norm_packed_reg(PackInfo pk, cons
     }
 }
 
+// Same, for LONG RNAs (T > 512): four workgroups per RNA, one per 32-channel chunk (thread = channel quad cq of the chunk x row group g of 32;
+// a wave reads 128 bytes of 8 rows per instruction).  With one workgroup per RNA a batch of seven 4,400-nt RNAs used 7 of the 256 CUs
+// (95 us per call on the config-3 epoch).  Per-channel arithmetic and its order over the row groups differ from the kernels above
+// (32 partial sums instead of 8): results agree to rounding, not bit for bit.
+__global__ void __launch_bounds__(256) k_graph_norm_packed_c4(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int t_tot) {
+    __shared__ float4 red[32][8];
+    __shared__ float4 stat[8];
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const size_t base = (size_t)pk.cu[b] * RN_D;
+    const int cl = threadIdx.x & 7, g = threadIdx.x >> 3, cq = 8 * blockIdx.y + cl;
+    const float4* xb = reinterpret_cast<const float4*>(x + base) + cq;
+    const float4* ab = add ? reinterpret_cast<const float4*>(add + base) + cq : nullptr;
+    auto ld = [&](int r) {
+        float4 v = xb[(size_t)r * 32];
+        if (ab) { float4 a = ab[(size_t)r * 32]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        return v;
+    };
+    auto fold = [&]() {
+        float4 t = red[0][cl];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) { const float4 u = red[i][cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        return t;
+    };
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = g; r < n; r += 32) { const float4 v = ld(r); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0) {
+        const float4 t = fold();
+        const float inv = 1.0f / (float)n;
+        stat[cl] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    __syncthreads();
+    const float4 mean = stat[cl];
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = g; r < n; r += 32) {
+        const float4 v = ld(r);
+        const float dx = v.x - mean.x, dy = v.y - mean.y, dz = v.z - mean.z, dw = v.w - mean.w;
+        ss.x = fmaf(dx, dx, ss.x); ss.y = fmaf(dy, dy, ss.y); ss.z = fmaf(dz, dz, ss.z); ss.w = fmaf(dw, dw, ss.w);
+    }
+    red[g][cl] = ss;
+    __syncthreads();
+    const float4 t = fold();
+    const float pad = (float)(t_tot - n), fn = (float)n;
+    float4 sd;
+    sd.x = sqrtf((t.x + pad * mean.x * mean.x) / fn + kSEPS); sd.y = sqrtf((t.y + pad * mean.y * mean.y) / fn + kSEPS);
+    sd.z = sqrtf((t.z + pad * mean.z * mean.z) / fn + kSEPS); sd.w = sqrtf((t.w + pad * mean.w * mean.w) / fn + kSEPS);
+    const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
+    float4* yb = reinterpret_cast<float4*>(y + base) + cq;
+#pragma unroll 4
+    for (int r = g; r < n; r += 32) {
+        const float4 v = ld(r);
+        float4 o;
+        o.x = (v.x - mean.x) / sd.x * sc.x + sh.x; o.y = (v.y - mean.y) / sd.y * sc.y + sh.y;
+        o.z = (v.z - mean.z) / sd.z * sc.z + sh.z; o.w = (v.w - mean.w) / sd.w * sc.w + sh.w;
+        yb[(size_t)r * 32] = o;
+    }
+}
+
 void launch_graph_norm_packed(const PackInfo& pk, const float* x, const float* add, float* y, const float* scale,
                               const float* shift, int t_tot, hipStream_t s) {
     // (same arithmetic, same summation order per thread: the register variant is bit-identical to the loop variant)
     if (pk.T <= 160) hipLaunchKernelGGL(k_graph_norm_packed_reg<20>, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
-    else hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
+    else if (pk.T <= 512) hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
+    else hipLaunchKernelGGL(k_graph_norm_packed_c4, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
 }
 
 // Stand-alone GraphNormalization on the reference's padded layout, any D, mask by value.
