@@ -342,6 +342,38 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, P
         unsigned long long prev = 0ull;              // keys are > 0 (distance >= 1e-3)
         const size_t pbase = (size_t)(base + i) * k;
         const size_t obase = ((size_t)b * T + i) * k;
+        if constexpr (G == 64) {
+            // Long rows (one wave per row, n / 64 candidates per lane): every lane keeps the smallest key of ITS candidates (j = lane mod 64) in a
+            // register; a round is a wave-min of those, and only the winner's candidate has to be renewed - by the whole wave, which re-reads the
+            // winner's n / 64 entries (two LDS reads per lane at 4,417 nt) and reduces again.  The plain form below rescans the entire row every round
+            // (69 LDS reads + key compares per lane and round at 4,417 nt: 1.6 ms per long batch of the config-3 epoch).  Same keys, same order.
+            auto wave_min = [](unsigned long long v) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(v, o, 64); v = other < v ? other : v; }
+                return v;
+            };
+            unsigned long long cand = ~0ull;
+            if (real)
+                for (int j = gl; j < n; j += 64) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(drow[j]) << 32) | (unsigned)j;
+                    cand = key < cand ? key : cand;
+                }
+            for (int s = 0; s < nreal; ++s) {                 // (G == 64: the wave has one row, nreal is wave-uniform)
+                const unsigned long long best = wave_min(cand);
+                const int jw = (int)(best & 0xffffffffu), w = jw & 63;
+                if (gl == 0) {
+                    nbr[pbase + s] = base + jw;
+                    if (eidx) eidx[obase + s] = jw;
+                }
+                unsigned long long nc = ~0ull;                 // the winner lane's next candidate: smallest key > best among j = w (mod 64)
+                for (int j = w + 64 * gl; j < n; j += 64 * 64) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(drow[j]) << 32) | (unsigned)j;
+                    if (key > best && key < nc) nc = key;
+                }
+                nc = wave_min(nc);
+                if (gl == w) cand = nc;
+            }
+        } else {
         for (int s = 0; s < nmax; ++s) {
             unsigned long long best = ~0ull;
             if (s < nreal) {
@@ -361,6 +393,7 @@ __global__ void __launch_bounds__(256) k_knn(const float* __restrict__ coords, P
                 nbr[pbase + s] = base + j;
                 if (eidx) eidx[obase + s] = j;
             }
+        }
         }
         if (real) {
             for (int s = nreal + gl; s < k; s += G) {
