@@ -231,6 +231,17 @@ __device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
 __device__ __forceinline__ bf16_t e_enc(float x) { return RN_E_F16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f2bf(x); }
 __device__ __forceinline__ float e_dec(bf16_t v) { return RN_E_F16 ? (float)__builtin_bit_cast(_Float16, v) : bf2f(v); }
 __device__ __forceinline__ f32x16 mfma_e(u32x4 a, u32x4 b, f32x16 c) { return RN_E_F16 ? mfma32h(a, b, c) : mfma32(a, b, c); }
+// Storage format of the per-residue P tables (k_node_update -> fused kernel): f16 of a P, one halfword per entry in the SAME entry order as the
+// (hi, lo) bf16 words of rounds 1-2 (entry 32 mb + m <-> accumulator row m of channel block mb).  The injection MFMA then is an f16 product of
+// (P, 0) against (1, 1); 11 significand bits against the 8 of the gathered Q rows beside it.  Halves the P bytes k_node_update writes (it is
+// HBM-bound on its table writes) and the fused kernel reads.  RN_P_F16=0 builds the word form (A/B).
+#ifndef RN_P_F16
+#define RN_P_F16 1
+#endif
+__device__ __forceinline__ unsigned p_pack2(float a, float b) {       // two P entries -> one word of two f16
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 
 // channel held by accumulator row m of a 32-row block when the output order is "natural per lane":
 // lane half h = (m>>2)&1, register i = (m&3) + 4*(m>>3)  ->  channel 32*blk + 16*h + i
@@ -540,8 +551,13 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         for (int s = 0; s < 8; ++s) ef[s] = efrag_ptr(e, b0, lane)[64 * s];
 #endif
         if (!SMALLK) {
+#if RN_P_F16
+            if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b0 * RN_D)[lane];
+            if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b0 * RN_D)[lane];
+#else
             if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b0 * RN_D + 2 * lane);
             if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b0 * RN_D + 2 * lane);
+#endif
             if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b0 * RN_D + 2 * lane);
         }
     }
@@ -624,22 +640,37 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     };
     auto load_p = [&](int b) {                         // !SMALLK: the residue's P words (coalesced 512 B rows), requested early ...
         if (SMALLK) return;
+#if RN_P_F16
+        if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b * RN_D)[lane];
+        if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b * RN_D)[lane];
+#else
         if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + 2 * lane);
         if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + 2 * lane);
+#endif
         if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b * RN_D + 2 * lane);
     };
     auto stage_p = [&]() {                             // ... through the wave's LDS slot ...
         if (SMALLK) return;
+#if RN_P_F16
+        if (DO_EDGE) lds_p[lane] = pn_e[0];                  // 128 halfwords per MLP
+        if (DO_MSG) lds_p[128 + lane] = pn_m[0];
+#else
         if (DO_EDGE) *reinterpret_cast<u32x2*>(lds_p + 2 * lane) = pn_e;
         if (DO_MSG) *reinterpret_cast<u32x2*>(lds_p + 128 + 2 * lane) = pn_m;
+#endif
         if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 256 + 2 * lane) = hn;
     };
     auto fetch_p = [&]() {                             // ... back as this lane's four words per MLP
         if (SMALLK) return;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
+#if RN_P_F16
+            if (DO_EDGE) pwe[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p)[32 * mb + r] : 0u;           // (P, 0): k = 1 carries nothing
+            if (DO_MSG) pwm[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p + 128)[32 * mb + r] : 0u;
+#else
             if (DO_EDGE) pwe[mb] = h == 0 ? lds_p[32 * mb + r] : 0u;
             if (DO_MSG) pwm[mb] = h == 0 ? lds_p[128 + 32 * mb + r] : 0u;
+#endif
         }
     };
     // ---- one MFMA of chain c (compile-time c, i), accumulating in T
@@ -648,6 +679,21 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     unsigned onesb = 0u;                               // ones column of this block's real edges (B operand, k = 0, 1)
     auto inject_p = [&](f32x16& T, const unsigned* ptab, unsigned pw, int mb) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if RN_P_F16
+        if (!SMALLK) { T = mfma32h(u32x4{pw, 0u, 0u, 0u}, u32x4{onesb ? 0x3C003C00u : 0u, 0u, 0u, 0u}, z); return; }      // f16 ones where the bf16 ones column has them
+        T = z;
+        for (int g = 0; g < npb; g += 8) {
+            u32x4 aw, bwv;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int qq = g + 4 * h + jj, node = blk * npb + qq;
+                aw[jj] = (qq < npb && node < ntot) ? (unsigned)reinterpret_cast<const bf16_t*>(ptab)[(size_t)node * RN_D + 32 * mb + r] : 0u;
+                bwv[jj] = (j >= 0 && q0 == qq) ? 0x3C003C00u : 0u;
+            }
+            T = mfma32h(aw, bwv, T);
+        }
+        return;
+#endif
         if (!SMALLK) { T = mfma32(u32x4{pw, 0u, 0u, 0u}, u32x4{onesb, 0u, 0u, 0u}, z); return; }
         // several residues per block: k-pair 4h + jj of group g carries residue g + 4h + jj against the indicator of its edges
         T = z;
@@ -1042,6 +1088,14 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
     auto qrow_of = [&](int j) { return j >= 0 ? (j > zero_row ? zero_row : j) : zero_row; };
     auto stage_p = [&](int b) {       // the residue's P rows -> f32 in the wave's slot (word w <-> channel ch_nat(w >> 5, w & 31); value = hi + lo)
         const int w0 = 2 * lane, ch0 = ch_nat(w0 >> 5, w0 & 31), ch1 = ch_nat((w0 + 1) >> 5, (w0 + 1) & 31);
+#if RN_P_F16
+        if (DO_EDGE) {
+            const f16x2 pw = __builtin_bit_cast(f16x2, reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b * RN_D)[lane]);
+            slot[ch0] = (float)pw[0]; slot[ch1] = (float)pw[1];
+        }
+        const f16x2 pm = __builtin_bit_cast(f16x2, reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b * RN_D)[lane]);
+        slot[128 + ch0] = (float)pm[0]; slot[128 + ch1] = (float)pm[1];
+#else
         if (DO_EDGE) {
             const u32x2 pw = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + w0);
             slot[ch0] = lo_bf(pw[0]) + hi_bf(pw[0]);
@@ -1050,6 +1104,7 @@ __global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, in
         const u32x2 pm = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + w0);
         slot[128 + ch0] = lo_bf(pm[0]) + hi_bf(pm[0]);
         slot[128 + ch1] = lo_bf(pm[1]) + hi_bf(pm[1]);
+#endif
     };
     u32x4 ef[4], q[4], hbf[4];
     int j = load_j(blk, 0);
@@ -1979,11 +2034,18 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
                 if (ob < 4) {
                     // P leaves as (hi, lo) bf16 words in accumulator-row order: word 32ob + m <-> channel ch_nat(ob, m),
                     // m = (i & 3) + 4h + 8(i >> 2) for register i - the A operand of the fused kernel's P-injection MFMA
+#if RN_P_F16
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(jbq.p) + (size_t)row * RN_D + 32 * ob + 4 * h;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        *reinterpret_cast<uint2*>(dst + 8 * v) = make_uint2(p_pack2(acc[4 * v], acc[4 * v + 1]), p_pack2(acc[4 * v + 2], acc[4 * v + 3]));
+#else
                     unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + (size_t)row * RN_D + 32 * ob + 4 * h;
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
                         *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
                                                                         split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
+#endif
                 } else {
                     u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + (size_t)row * RN_D + 32 * (ob - 4) + 16 * h);
                     dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
@@ -2144,11 +2206,18 @@ __global__ void __launch_bounds__(256, 1) k_node_rna(PackInfo pk, const float* _
                 for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
                 if (ok) {
                     if (ob < 4) {
+#if RN_P_F16
+                        bf16_t* dst = reinterpret_cast<bf16_t*>(jbq.p) + row * RN_D + 32 * ob + 4 * h;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            *reinterpret_cast<uint2*>(dst + 8 * v) = make_uint2(p_pack2(acc[4 * v], acc[4 * v + 1]), p_pack2(acc[4 * v + 2], acc[4 * v + 3]));
+#else
                         unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + row * RN_D + 32 * ob + 4 * h;
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
                             *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
                                                                             split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
+#endif
                     } else {
                         u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + row * RN_D + 32 * (ob - 4) + 16 * h);
                         dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
