@@ -10,6 +10,6 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sqA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
 run grbm GRBM_GUI_ACTIVE
-for k in "k_emm128<true, unsigned short, 1" "k_emm128<true, unsigned short, 0, true, true" "k_emm128<false, unsigned short, 2" "k_emm128<false, unsigned short, 3" "k_emm_tn" "k_eseg_mean_bwd" "k_epq_bwd"; do
+for k in "k_emm_fwd2<false, true>" "k_emm_fwd2<true, true>" "k_emm_bwd2<1>" "k_emm_bwd2<2>" "k_emm_bwd1x2" "k_eseg_mean(" "k_epq_bwd" "k_attn_fwd_m16" "k_attn_bwd_q_m16" "k_attn_bwd_kv_m16"; do
   echo "== $k"; python3 $ROOT/tools/pmc_summary.py $OUT "$k"
 done
