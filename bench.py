@@ -56,7 +56,8 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3
-C4_RNAS, C4_LEN, C4_MICRO = 10000, 200, 2500
+C4_RNAS, C4_LEN = 10000, 200
+C4_MICRO = int(os.environ.get("RNAMPNN_C4_MICRO", "2500"))      # RNAs per forward of a rank's share (tuning knob)
 
 
 def parse(argv=None):
