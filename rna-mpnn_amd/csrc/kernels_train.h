@@ -99,20 +99,24 @@ bool tm_gemm_nn_pq(const TRows& rows, const float* dpq, const float* w0, float* 
 // forward of a depth-2 per-edge MLP in one kernel (the hidden activation stays in registers; pre1 / pre2 written once as the tape;
 // pre1 = null: not kept)
 void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, const float* W2, int ldw2, const float* bias2, tb16* pre1,
-                 tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s);
+                 tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s, bool g2tape = false);   // g2tape (edge update only): pre2 receives gelu'(pre2) * mask(site2)
 // fused pair of a first Linear's backward: dW += dY^T X, DE += dY . W   (one pass over dY)
 void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, const float* W, int ldw, float* dW, int ldw_out,
                   const TScratch& sc, hipStream_t s);
 // fused pair of a depth-2 MLP's backward: dW += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask   (one pass over dY and PRE)
 // `from` (optional): d pre2 is formed on the fly while the tile is staged - mode 1: dY = d e_out, d pre2 = valid ? dY gelu'(pre2) mask(site2) : 0
 // (the edge update's residual backward); mode 2: d pre2 = valid ? dagg[row / k] inv_cnt[row / k] gelu'(pre2) mask(site2) : 0 (the message mean's)
-struct EBwd2Src { int mode; const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; };
+// g2tape: the `pre2` tensor holds gelu'(pre2) * mask(site2) as the forward left it (k_emm_fwd2 / k_eseg_mean, below) instead of pre2: the staging pass
+// multiplies, where it evaluated a sigmoid, an exp2 and a dropout hash per element
+struct EBwd2Src { int mode; const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; int g2tape; };
 void te_gemm_bwd1x2(const TRows& rows, const tb16* dY1, const tb16* dY2, const tb16* X, tb16* DE, const float* W1, const float* W2, int ldw,
                     float* dW1, float* dW2, int ldw_out, const TScratch& sc, hipStream_t s);
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
                   const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from = nullptr);
 void te_inv_count(const PackInfo& pk, int k, const int* nbr, float* inv_cnt, hipStream_t s);   // 1 / max(#valid slots, 1) per residue
-void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s);
+// g2_out (optional, may alias pre2): gelu'(pre2) * mask(site) per element - what the message MLP's backward needs of pre2
+void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s,
+                 tb16* g2_out = nullptr);
 void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_res_bwd(const PackInfo& pk, int k, const int* nbr, const tb16* de, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s);
 void te_edge_pq_bwd(const PackInfo& pk, int k, const tb16* dpre1, const int* start, const int* list, float* dpq, hipStream_t s);

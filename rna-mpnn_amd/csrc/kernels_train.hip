@@ -1815,6 +1815,7 @@ void te_gemm_pq(const TRows& rows, const float* h, const float* w0, const float*
 // block cb): the hidden activation never leaves the registers, pre1 / pre2 are written once as the tape, and the e tile that was the
 // operand of the first Linear is still in registers when the edge update needs it.  Against the two-kernel form this saves the read of pre1
 // and (edge update) the second read of e.  Both weight images live in LDS (64 KiB, two workgroups per CU).
+__device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d);
 struct Emm2Args {
     TRows rows;
     const tb16* X;                   // e [R][128]
@@ -1824,6 +1825,7 @@ struct Emm2Args {
     tb16* pre1; tb16* pre2;
     EFuse f;                         // P, Q, nbr, k, zero_row ; res_out (optional), site2
     TDrop dr; unsigned site;         // dropout site of the hidden activation
+    int g2tape;                      // RES: pre2 receives gelu'(pre2) * mask(site2) - all the backward needs of it - instead of pre2
 };
 template <bool RES, bool TAPE1>       // TAPE1: pre1 is written (training tape); inference callers keep only pre2
 // tape stores (written once, read a whole backward later): TE_EXP_NT_TAPE builds them as non-temporal stores - measured 30.3 ms per step at the C2
@@ -1926,25 +1928,35 @@ __global__ void __launch_bounds__(256, 2) k_emm_fwd2(Emm2Args a) {
             const tf32x4 b0 = *reinterpret_cast<const tf32x4*>(lds_bias + c), b1 = *reinterpret_cast<const tf32x4*>(lds_bias + c + 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = acc[cb][8 * g + q] + b0[q]; v[4 + q] = acc[cb][8 * g + 4 + q] + b1[q]; }
-            if (rok) TE_TAPE_STORE(a.pre2 + (size_t)row * 128 + c, tpack8(v));
             if constexpr (RES) {
-                float ei[8];
+                float ei[8], dm[8];
                 unpack8(xe[u], ei);
-                if (j >= 0) {
-                    float dm[8];
-                    drop8(a.dr, key2, (unsigned)row * 16u + 2 * u + h, dm);
+                drop8(a.dr, key2, (unsigned)row * 16u + 2 * u + h, dm);
+                if (a.g2tape) {                  // (uniform) the tape gets gelu' * mask, evaluated on the unrounded pre-activation, sharing the sigmoid with the update
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float g, d;
+                        gelu_both_fast(v[q], g, d);
+                        if (j >= 0) ei[q] += g * dm[q];
+                        v[q] = d * dm[q];
+                    }
+                } else if (j >= 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) ei[q] += gelu_fast(v[q]) * dm[q];
                 }
+                if (rok) TE_TAPE_STORE(a.pre2 + (size_t)row * 128 + c, tpack8(v));
                 if (rok) *reinterpret_cast<tu32x4*>(a.f.res_out + (size_t)row * 128 + c) = tpack8(ei);
+            } else {
+                if (rok) TE_TAPE_STORE(a.pre2 + (size_t)row * 128 + c, tpack8(v));
             }
         }
     }
 }
 // pre1 = X . W1^T + P[row / k] + Q[nbr[row]] ; pre2 = drop(gelu(pre1), site) . W2^T + bias2 ; [res_out = X + valid drop(gelu(pre2), site2)]
 void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, const float* W2, int ldw2, const float* bias2, tb16* pre1,
-                 tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s) {
+                 tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s, bool g2tape) {
     Emm2Args a;
+    a.g2tape = (g2tape && f.res_out) ? 1 : 0;
     a.rows = rows; a.X = X; a.W1 = W1; a.ldw1 = ldw1; a.W2 = W2; a.ldw2 = ldw2; a.bias2 = bias2; a.pre1 = pre1; a.pre2 = pre2; a.f = f;
     a.dr = dr; a.site = site;
     a.wimg1 = wimg_lookup(W1, ldw1, true, 1); a.wimg2 = wimg_lookup(W2, ldw2, true, 1);
@@ -2098,7 +2110,7 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d) {   
 // dY = d e_out - the residual backward formed while the tile is staged instead of by a kernel of its own (one read and one write of an
 // [E][128] tensor less).  2 (message mean, mpnn.py:212-219): d pre2 = valid ? dagg[row / k] / cnt[row / k] * gelu'(PRE2) * mask(site2) : 0.
 // The staged values are rounded to bf16 exactly as the stand-alone kernels stored them: results are bit-identical to the two-kernel form.
-struct Bwd2Src { const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; };
+struct Bwd2Src { const tb16* pre2; const int* nbr; const float* dagg; const float* inv_cnt; int k; unsigned site2; int g2tape; };
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __restrict__ dY, const tb16* __restrict__ PRE, tb16* __restrict__ DX,
         const float* __restrict__ W, int ldw, const unsigned short* __restrict__ wimg, float* __restrict__ part, size_t pstride,
@@ -2176,9 +2188,14 @@ __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __r
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { up[q] = ga[i][q] * ic[i]; up[4 + q] = gb[i][q] * ic[i]; }
                 }
-                drop8(dr, key2, (unsigned)m * 16u + ch, dm2);
+                if (src.g2tape) {                // (uniform) the tape holds gelu'(pre2) * mask already
 #pragma unroll
-                for (int q = 0; q < 8; ++q) up[q] = MODE == 1 ? up[q] * (gelu_d_fast(p2[q]) * dm2[q]) : up[q] * gelu_d_fast(p2[q]) * dm2[q];   // (the stand-alone kernels' association)
+                    for (int q = 0; q < 8; ++q) up[q] *= p2[q];
+                } else {
+                    drop8(dr, key2, (unsigned)m * 16u + ch, dm2);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) up[q] = MODE == 1 ? up[q] * (gelu_d_fast(p2[q]) * dm2[q]) : up[q] * gelu_d_fast(p2[q]) * dm2[q];   // (the stand-alone kernels' association)
+                }
                 dy4[i] = jv[i] >= 0 ? tpack8(up) : z4;
             }
         }
@@ -2521,9 +2538,9 @@ void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, 
     const int rps = ((rows.maxrows + splits - 1) / splits + 63) / 64 * 64;
     const size_t pstride = mk + (dbias ? 128 : 0);
     float* tmp = sc.p + (size_t)splits * pstride;
-    Bwd2Src src{nullptr, nullptr, nullptr, nullptr, 1, 0u};
+    Bwd2Src src{nullptr, nullptr, nullptr, nullptr, 1, 0u, 0};
     const int mode = from ? from->mode : 0;
-    if (from) src = Bwd2Src{from->pre2, from->nbr, from->dagg, from->inv_cnt, from->k, from->site2};
+    if (from) src = Bwd2Src{from->pre2, from->nbr, from->dagg, from->inv_cnt, from->k, from->site2, from->g2tape};
 #define BWD2_GO(M) hipLaunchKernelGGL(k_emm_bwd2<M>, dim3(1, 1, splits), dim3(256), 0, s, rows, dY, PRE, DX, W, ldw, wimg_lookup(W, ldw, false, 1), \
                                        sc.p, pstride, rps, dr, site, dbias ? sc.p + mk : (float*)nullptr, src)
     if (mode == 1) BWD2_GO(1); else if (mode == 2) BWD2_GO(2); else BWD2_GO(0);
@@ -2836,8 +2853,8 @@ int te_attention_bwd(const PackInfo& pk, const float* qkv, const float* O, const
 // One wave per residue, lane = two adjacent channels.  The k validity flags are taken in ONE load + ballot (a per-slot `if (nbr >= 0)` in the
 // loop is a dependent load -> branch -> load chain per slot: 83 % of the wave cycles were waits), the row loads are unconditional and go
 // out in batches of the unrolled loop.
-__global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const tb16* __restrict__ pre2,
-                                                   const float* __restrict__ hin, float* __restrict__ out, TDrop dr, unsigned site) {
+__global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int* __restrict__ nbr, const tb16* pre2,
+                                                   const float* __restrict__ hin, float* __restrict__ out, TDrop dr, unsigned site, tb16* g2_out) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= pk.cu[pk.B]) return;
     const int lane = threadIdx.x & 63, c = 2 * lane;
@@ -2852,8 +2869,16 @@ __global__ void __launch_bounds__(256) k_eseg_mean(PackInfo pk, int k, const int
         float m0, m1;
         drop_pair(dr, key, (unsigned)(p * k + sl) * 64u + lane, m0, m1);
         const bool valid = (vm >> sl) & 1ull;               // (a select, not a multiply by 0: an absent slot's row may hold anything)
-        s0 += valid ? gelu_fast(tbf_lo(w)) * m0 : 0.f;
-        s1 += valid ? gelu_fast(tbf_hi(w)) * m1 : 0.f;
+        if (g2_out) {                                       // (uniform) leave gelu' * mask for the backward, in place of pre2 when the two alias
+            float g0, d0, g1, d1;
+            gelu_both_fast(tbf_lo(w), g0, d0); gelu_both_fast(tbf_hi(w), g1, d1);
+            s0 += valid ? g0 * m0 : 0.f;
+            s1 += valid ? g1 * m1 : 0.f;
+            *reinterpret_cast<unsigned*>(g2_out + (size_t)p * k * RN_D + c + (size_t)sl * RN_D) = valid ? tpack2(d0 * m0, d1 * m1) : 0u;
+        } else {
+            s0 += valid ? gelu_fast(tbf_lo(w)) * m0 : 0.f;
+            s1 += valid ? gelu_fast(tbf_hi(w)) * m1 : 0.f;
+        }
     }
     const float inv = 1.0f / (float)(cnt > 0 ? cnt : 1);
     const tf32x2 hv = *reinterpret_cast<const tf32x2*>(hin + (size_t)p * RN_D + c);
@@ -2893,8 +2918,9 @@ __global__ void k_inv_count(PackInfo pk, int k, const int* __restrict__ nbr, flo
 void te_inv_count(const PackInfo& pk, int k, const int* nbr, float* inv_cnt, hipStream_t s) {
     hipLaunchKernelGGL(k_inv_count, dim3((pk.Nmax + 255) / 256), dim3(256), 0, s, pk, k, nbr, inv_cnt);
 }
-void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s) {
-    hipLaunchKernelGGL(k_eseg_mean, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, pre2, h, out, dr, site);
+void te_seg_mean(const PackInfo& pk, int k, const int* nbr, const tb16* pre2, const float* h, float* out, const TDrop& dr, unsigned site, hipStream_t s,
+                 tb16* g2_out) {
+    hipLaunchKernelGGL(k_eseg_mean, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, pre2, h, out, dr, site, g2_out);
 }
 void te_seg_mean_bwd(const PackInfo& pk, int k, const int* nbr, const float* dagg, const tb16* pre2, tb16* dpre2, const TDrop& dr, unsigned site, hipStream_t s) {
     hipLaunchKernelGGL(k_eseg_mean_bwd, dim3((pk.Nmax + 3) / 4), dim3(256), 0, s, pk, k, nbr, dagg, pre2, dpre2, dr, site);
