@@ -1816,6 +1816,7 @@ void te_gemm_pq(const TRows& rows, const float* h, const float* w0, const float*
 // operand of the first Linear is still in registers when the edge update needs it.  Against the two-kernel form this saves the read of pre1
 // and (edge update) the second read of e.  Both weight images live in LDS (64 KiB, two workgroups per CU).
 __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& d);
+#define TE_DROPPED (-1.0e4f)         // taped in place of a dropped pre-activation: gelu_fast, gelu_d_fast and gelu_both_fast give exactly (-)0 there
 struct Emm2Args {
     TRows rows;
     const tb16* X;                   // e [R][128]
@@ -1826,6 +1827,7 @@ struct Emm2Args {
     EFuse f;                         // P, Q, nbr, k, zero_row ; res_out (optional), site2
     TDrop dr; unsigned site;         // dropout site of the hidden activation
     int g2tape;                      // RES: pre2 receives gelu'(pre2) * mask(site2) - all the backward needs of it - instead of pre2
+    int p1mask;                      // pre1 is taped with its DROPPED elements replaced by TE_DROPPED (gelu = gelu' = 0 there): the backward needs no hash
 };
 template <bool RES, bool TAPE1>       // TAPE1: pre1 is written (training tape); inference callers keep only pre2
 // tape stores (written once, read a whole backward later): TE_EXP_NT_TAPE builds them as non-temporal stores - measured 30.3 ms per step at the C2
@@ -1912,9 +1914,18 @@ __global__ void __launch_bounds__(256, 2) k_emm_fwd2(Emm2Args a) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = acc[cb][8 * g + q] + pv[q] + qv[q];
             const tu32x4 y = tpack8(v);
-            if (TAPE1 && rok) TE_TAPE_STORE(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h, y);
-            unpack8(y, v);
             drop8(a.dr, key1, (unsigned)row * 16u + 2 * u + h, dm);
+            if (TAPE1 && rok) {
+                if (a.p1mask) {                  // (uniform)
+                    float vm[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vm[q] = dm[q] != 0.f ? v[q] : TE_DROPPED;
+                    TE_TAPE_STORE(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h, tpack8(vm));
+                } else {
+                    TE_TAPE_STORE(a.pre1 + (size_t)row * 128 + 16 * u + 8 * h, y);
+                }
+            }
+            unpack8(y, v);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = gelu_fast(v[q]) * dm[q];
             xh[u] = rok ? tpack8(v) : tu32x4{0u, 0u, 0u, 0u};
@@ -1957,6 +1968,7 @@ void te_mlp2_fwd(const TRows& rows, const tb16* X, const float* W1, int ldw1, co
                  tb16* pre2, const EFuse& f, const TDrop& dr, unsigned site, hipStream_t s, bool g2tape) {
     Emm2Args a;
     a.g2tape = (g2tape && f.res_out) ? 1 : 0;
+    a.p1mask = (g2tape && pre1) ? 1 : 0;
     a.rows = rows; a.X = X; a.W1 = W1; a.ldw1 = ldw1; a.W2 = W2; a.ldw2 = ldw2; a.bias2 = bias2; a.pre1 = pre1; a.pre2 = pre2; a.f = f;
     a.dr = dr; a.site = site;
     a.wimg1 = wimg_lookup(W1, ldw1, true, 1); a.wimg2 = wimg_lookup(W2, ldw2, true, 1);
@@ -2206,9 +2218,14 @@ __global__ void __launch_bounds__(256, 2) k_emm_bwd2(TRows rows, const tb16* __r
             const tu32x4 va = ok ? dy4[i] : z4;
             float v[8], dm[8], a1[8], gp[8];
             unpack8(b0[i], v);
-            drop8(dr, key, (unsigned)m * 16u + ch, dm);
+            if (MODE != 0 && src.g2tape) {       // (uniform) dropped elements are TE_DROPPED on the tape: both functions vanish there, no hash
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { float g, d; gelu_both_fast(v[q], g, d); a1[q] = g * dm[q]; gp[q] = d * dm[q]; }
+                for (int q = 0; q < 8; ++q) { float g, d; gelu_both_fast(v[q], g, d); a1[q] = g * dr.scale; gp[q] = d * dr.scale; }
+            } else {
+                drop8(dr, key, (unsigned)m * 16u + ch, dm);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { float g, d; gelu_both_fast(v[q], g, d); a1[q] = g * dm[q]; gp[q] = d * dm[q]; }
+            }
             *reinterpret_cast<tu32x4*>(tA + (rg + 16 * i) * TN_PITCH + 8 * ch) = va;
             *reinterpret_cast<tu32x4*>(tB + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? tpack8(a1) : z4;
             *reinterpret_cast<tu32x4*>(tG + (rg + 16 * i) * TN_PITCH + 8 * ch) = ok ? tpack8(gp) : z4;
