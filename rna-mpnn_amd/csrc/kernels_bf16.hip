@@ -1894,6 +1894,28 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
             q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
         }
         Q = block_sum(q);
+    } else if (n <= 256) {  // (C4: 200 nt) the same with eight rows per thread
+        float4 v[8], a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int r = g + 32 * i, rc = r < n ? r : n - 1; v[i] = xb[(size_t)rc * 32]; }
+        if (ab) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int r = g + 32 * i, rc = r < n ? r : n - 1; a[i] = ab[(size_t)rc * 32]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
+        }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (g + 32 * i < n) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        S = block_sum(s);
+        const float4 mu = make_float4(S.x / fn, S.y / fn, S.z / fn, S.w / fn);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (g + 32 * i < n) {
+            const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+            q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+        }
+        Q = block_sum(q);
     } else {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = g; r < n; r += 32) {

@@ -966,6 +966,7 @@ void launch_graph_norm_packed(const PackInfo& pk, const float* x, const float* a
                               const float* shift, int t_tot, hipStream_t s) {
     // (same arithmetic, same summation order per thread: the register variant is bit-identical to the loop variant)
     if (pk.T <= 160) hipLaunchKernelGGL(k_graph_norm_packed_reg<20>, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
+    else if (pk.T <= 256) hipLaunchKernelGGL(k_graph_norm_packed_reg<32>, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);      // (C4: 200 nt)
     else if (pk.T <= 512) hipLaunchKernelGGL(k_graph_norm_packed, dim3(pk.B), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
     else hipLaunchKernelGGL(k_graph_norm_packed_c4, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, y, scale, shift, t_tot);
 }
