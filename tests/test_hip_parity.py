@@ -288,6 +288,10 @@ def test_bf16_path_within_tolerance(golden, name):
     assert np.isfinite(logits).all()
     err = np.abs(logits - arrs["logits"]).max()
     assert err < bf16_tol(arrs["logits"], arrs["mask"]), f"{name}: |dlogit| = {err:.3e}"
+    if int(hp.get("num_res_neighbours", 30)) > 16:
+        # the one-residue-per-block kernel of the BASELINE configurations (k = 30): measured 7.0e-3 .. 7.3e-3 on these goldens since e and the P tables
+        # are stored as f16 (2.2e-2 in round 2); half the generic floor is asserted.  (k <= 16 packs several residues per block: 1.8e-2 measured.)
+        assert err < 0.5 * BF16_LOGIT_TOL, f"{name}: |dlogit| = {err:.3e}"
     assert (logits[arrs["mask"] == 0] == 0).all()
     labels = arrs["labels"]
     valid = arrs["mask"] > 0
