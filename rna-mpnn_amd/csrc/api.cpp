@@ -63,7 +63,6 @@ struct Mlp2 {                 // message_layers / edge_layers of one ResMPNN
     size_t pq_bp;             // derived f32 bias of Linear 0 in the order of that image's P rows
     size_t img;               // derived bf16 fragment image of (Wc, W2) for the fused edge kernel
     size_t b2p;               // derived f32 bias of Linear 1 in the kernel's channel order
-    size_t img16, b2p16;      // the same for the 16-edge-tile fused kernel
 };
 struct MpnnLayer { int gn_scale, gn_shift; Mlp2 msg, edge; };
 
@@ -108,26 +107,8 @@ struct rnampnn_ctx {
     const unsigned long long* seed_dev = nullptr;   // rnampnn_set_seed_source: the training kernels read the dropout seed from device memory
     WImageCache* wimg = nullptr;   // prebuilt weight-fragment images of the bf16-mixed trainer (kernels_train.h)
     bool raw_external = false;     // raw_arena is the caller's flat parameter buffer (rnampnn_use_weight_arena)
-    // fork / join inside one forward: independent branches of the node stack run on auxiliary streams beside the
-    // latency-bound kernels of the caller's stream (k-NN at the start, the small attention kernels at the end)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t fj[4] = {nullptr, nullptr, nullptr, nullptr};
-    int overlap = -1;              // -1: not decided yet.  OFF unless RNAMPNN_OVERLAP=1: measured null on C2 (2.602 vs 2.607 ms/step) -
-                                   // the branches cannot co-reside: k_ffn_chain needs 135 KiB of a CU's LDS, which the
-                                   // 5 resident k-NN workgroups (53 KiB) or a GEMM workgroup (36 KiB) do not leave free
 };
 
-static bool overlap_ready(rnampnn_ctx* c) {
-    if (c->overlap < 0) {
-        const char* e = getenv("RNAMPNN_OVERLAP");
-        c->overlap = (e && e[0] == '1') ? 1 : 0;
-        if (c->overlap) {
-            for (auto& a : c->aux) if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) c->overlap = 0;
-            for (auto& ev : c->fj) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) c->overlap = 0;
-        }
-    }
-    return c->overlap == 1;
-}
 
 static int add_raw(rnampnn_ctx* c, const std::string& key, int64_t numel) {
     RawT t{key, numel, c->raw_floats, false};
@@ -220,8 +201,6 @@ static Mlp2 make_mlp2(rnampnn_ctx* c, const std::string& prefix, int depth) {
     m.pq_bp = add_der(c, RN_D * sizeof(float));
     m.img = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
     m.b2p = add_der(c, RN_D * sizeof(float));
-    m.img16 = add_der(c, (size_t)2 * RN_D * RN_D * sizeof(bf16_t));
-    m.b2p16 = add_der(c, RN_D * sizeof(float));
     return m;
 }
 
@@ -335,8 +314,6 @@ extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t
 extern "C" int rnampnn_destroy(rnampnn_handle h) {
     if (!h) return RNAMPNN_OK;
     for (auto& e : h->ev) (void)hipEventDestroy(e);
-    for (auto& a : h->aux) if (a) (void)hipStreamDestroy(a);
-    for (auto& e : h->fj) if (e) (void)hipEventDestroy(e);
     if (h->raw_arena && !h->raw_external) (void)hipFree(h->raw_arena);
     if (h->der_arena) (void)hipFree(h->der_arena);
     t_wimg_destroy(h->wimg);
@@ -421,8 +398,6 @@ static void finalize_mlp2(rnampnn_ctx* c, const Mlp2& m, bool is_edge, hipStream
         launch_build_pq_image(w0, rawp(c, m.b[0]), one ? 1 : 0, derp<bf16_t>(c, m.pq_img), derp<float>(c, m.pq_bp), s);
         launch_build_mlp_image(w0 + 2 * RN_D, 3 * RN_D, one ? nullptr : rawp(c, m.w[1]), RN_D, one ? nullptr : rawp(c, m.b[1]),
                                is_edge ? 1 : 0, derp<bf16_t>(c, m.img), derp<float>(c, m.b2p), s);
-        if (!one) launch_build_mlp16_image(w0 + 2 * RN_D, 3 * RN_D, rawp(c, m.w[1]), RN_D, rawp(c, m.b[1]), is_edge ? 1 : 0,
-                                           derp<bf16_t>(c, m.img16), derp<float>(c, m.b2p16), s);
     }
 }
 
@@ -476,9 +451,9 @@ extern "C" int rnampnn_finalize_weights(rnampnn_handle h, void* stream) {
 // ------------------------------------------------------------------------------------------
 struct Ws {                       // workspace carve (all offsets 256-byte aligned)
     int *len, *cu, *node_b, *nbr;
-    float *geom, *geomh, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *rb0, *rb1, *logits_p;
+    float *geom, *geomh, *raw_p, *hA, *hB, *pq_e, *pq_m, *s0, *s1, *n0, *n1, *n2, *logits_p;
     float* coef;                  // fast path: per-RNA GraphNorm affine coefficients [B][256]
-    bf16_t *q_e, *q_m;            // fast path: bf16 Q tables [(Nmax+1)][128]; pq_* then hold P as [(Nmax+1)][128] f32
+    bf16_t *p_e, *p_m, *q_e, *q_m;   // fast path: the f16 P / Q tables [(Nmax+1)][128] of the two first Linears (pq_* are the f32 path's [P | Q])
     void* e;                      // f32 or bf16 [Nmax*k][128]
     float* big;                   // [Nmax*k][128] f32 scratch for the stage API / edge taps
     size_t total;
@@ -500,18 +475,19 @@ static size_t carve(const rnampnn_ctx* c, int B, size_t Nmax, char* base, Ws* w)
     r.raw_p = (float*)take(Nmax * RN_RAWP * sizeof(float));
     r.hA = (float*)take((Nmax + 1) * RN_D * sizeof(float));
     r.hB = (float*)take((Nmax + 1) * RN_D * sizeof(float));
-    r.pq_e = (float*)take((Nmax + 1) * 256 * sizeof(float));
-    r.pq_m = (float*)take((Nmax + 1) * 256 * sizeof(float));
+    const bool fastp = c->cfg.precision == RNAMPNN_PREC_BF16;
+    r.pq_e = (float*)take(fastp ? (Nmax + 1) * 2 * RN_D * sizeof(float) : (Nmax + 1) * 256 * sizeof(float));   // (fast path: the read-out stage API packs its input here)
+    r.pq_m = (float*)take(fastp ? 0 : (Nmax + 1) * 256 * sizeof(float));
     r.coef = (float*)take((size_t)B * 256 * sizeof(float));
-    r.q_e = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
-    r.q_m = (bf16_t*)take((Nmax + 1) * RN_D * sizeof(bf16_t));
+    r.p_e = (bf16_t*)take(fastp ? (Nmax + 1) * RN_D * sizeof(bf16_t) : 0);
+    r.p_m = (bf16_t*)take(fastp ? (Nmax + 1) * RN_D * sizeof(bf16_t) : 0);
+    r.q_e = (bf16_t*)take(fastp ? (Nmax + 1) * RN_D * sizeof(bf16_t) : 0);
+    r.q_m = (bf16_t*)take(fastp ? (Nmax + 1) * RN_D * sizeof(bf16_t) : 0);
     r.s0 = (float*)take(Nmax * F * sizeof(float));
     r.s1 = (float*)take(Nmax * F * sizeof(float));
     r.n0 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n1 = (float*)take(Nmax * RN_D * sizeof(float));
     r.n2 = (float*)take(Nmax * RN_D * sizeof(float));
-    r.rb0 = (float*)take(Nmax * RN_D * sizeof(float));        // raw-embedding branch (runs beside the post-fusion stack)
-    r.rb1 = (float*)take(Nmax * RN_D * sizeof(float));
     r.logits_p = (float*)take(Nmax * 4 * sizeof(float));
     r.e = (void*)take(c->cfg.precision == RNAMPNN_PREC_BF16 ? efrag_bytes((int)Nmax, (int)k) : Nmax * k * RN_D * esz);
     r.big = (float*)take(Nmax * k * RN_D * sizeof(float));
@@ -604,14 +580,20 @@ static void run_ffn(Run& r, const Chain& ch, const std::vector<Lin>& ffn, const 
     }
 }
 
-static void node_pq(Run& r, const Mlp2& m, const float* h, float* pq, bf16_t* q) {
+static NodeJob node_job(rnampnn_ctx* c, const Mlp2& m, bf16_t* p, bf16_t* q) {
+    NodeJob j;
+    j.img = derp<bf16_t>(c, m.pq_img); j.bias = derp<float>(c, m.pq_bp); j.p = p; j.q = q; j.p_efrag = m.depth == 1;
+    return j;
+}
+// the per-residue parts [P | Q] of one MLP's first Linear: `edge` selects the workspace tables of the edge-update / message MLP
+static void node_pq(Run& r, const Mlp2& m, const float* h, bool edge) {
     rnampnn_ctx* c = r.c;
-    if (r.fast)     // the fused node kernel without residual / norm: P -> split-bf16 words (in pq), Q -> bf16 (in q)
-        launch_node_update(r.pk, h, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, derp<bf16_t>(c, m.pq_img),
-                           derp<float>(c, m.pq_bp), pq, q, nullptr, nullptr, nullptr, nullptr, r.s);
+    if (r.fast)     // the fused node kernel without residual / norm
+        launch_node_update(r.pk, h, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1,
+                           node_job(c, m, edge ? r.w.p_e : r.w.p_m, edge ? r.w.q_e : r.w.q_m), NodeJob{}, r.s);
     else
         launch_gemm_f32(r.ntot(), r.pk.Nmax, h, RN_D, RN_D, nullptr, 0, 0, derp<float>(c, m.pq_t),
-                        derp<float>(c, m.pq_b), 256, 0, nullptr, 0, pq, 256, r.s);
+                        derp<float>(c, m.pq_b), 256, 0, nullptr, 0, edge ? r.w.pq_e : r.w.pq_m, 256, r.s);
 }
 
 static MpnnW32 w32(rnampnn_ctx* c, const Mlp2& m) {
@@ -626,7 +608,6 @@ static MpnnWB wbf(rnampnn_ctx* c, const Mlp2& m) {
     MpnnWB w;
     w.img = derp<bf16_t>(c, m.img);
     w.b2p = derp<float>(c, m.b2p);
-    if (m.depth > 1) { w.img16 = derp<bf16_t>(c, m.img16); w.b2p16 = derp<float>(c, m.b2p16); }
     return w;
 }
 
@@ -637,7 +618,7 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
     if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
     if (r.fast) {
-        launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.pq_e, r.w.q_e, r.w.pq_m,
+        launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.p_e, r.w.q_e, r.w.p_m,
                          r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1,
                          wm ? h_in : nullptr, r.s);      // h_pre = h_in + mean of the messages (both paths)
     } else {
@@ -684,9 +665,9 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
     auto add = [&](void* p, size_t bytes) { z.ptr[z.n] = p; z.words[z.n] = (unsigned)(bytes / 4); ++z.n; };
     add(r.w.hA + Nmax * RN_D, RN_D * sizeof(float));
     add(r.w.hB + Nmax * RN_D, RN_D * sizeof(float));
-    if (r.fast) {   // fast-path tables are [N+1][128]: P words inside pq_*, Q bf16
-        add(r.w.pq_e + Nmax * RN_D, RN_D * sizeof(float));
-        add(r.w.pq_m + Nmax * RN_D, RN_D * sizeof(float));
+    if (r.fast) {   // fast-path tables are f16 [N+1][128]
+        add(r.w.p_e + Nmax * RN_D, RN_D * sizeof(bf16_t));
+        add(r.w.p_m + Nmax * RN_D, RN_D * sizeof(bf16_t));
         add(r.w.q_e + Nmax * RN_D, RN_D * sizeof(bf16_t));
         add(r.w.q_m + Nmax * RN_D, RN_D * sizeof(bf16_t));
     } else {
@@ -740,29 +721,19 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
 
     // ---- ResFeature.forward (feature.py:588-592)
     launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, r.fast ? w.geomh : nullptr, s);
-    const bool ovl = overlap_ready(c);
     const bool fused_first = r.fast && io->stop_after != 1;
-    // fork: the node-embedding branch (raw_project -> RNABert -> GraphNorm [-> P|Q of layer 1]) needs only k_geom's output; it
-    // runs on an auxiliary stream beside the latency-bound k-NN kernel (disjoint workspace buffers) and joins before layer 1
-    if (ovl) { (void)hipEventRecord(c->fj[0], s); (void)hipStreamWaitEvent(c->aux[0], c->fj[0], 0); r.s = c->aux[0]; }
     gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
     rc = run_bert(r, c->emb, w.n0, w.n1);
     if (!rc) {
         if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass
             launch_node_update(r.pk, w.n1, nullptr, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, w.coef, w.hA, 1,
-                               derp<bf16_t>(c, c->mpnn[0].msg.pq_img), derp<float>(c, c->mpnn[0].msg.pq_bp), w.pq_m, w.q_m,
-                               nullptr, nullptr, nullptr, nullptr, r.s);
+                               node_job(c, c->mpnn[0].msg, w.p_m, w.q_m), NodeJob{}, r.s);
         else
             launch_graph_norm_packed(r.pk, w.n1, nullptr, w.hA, rawp(c, c->feat_gn_scale), rawp(c, c->feat_gn_shift), t_norm, r.s);
     }
-    if (ovl) { (void)hipEventRecord(c->fj[1], c->aux[0]); r.s = s; }
-    auto join0 = [&]() { if (ovl) (void)hipStreamWaitEvent(s, c->fj[1], 0); };
-    if (rc) { join0(); return rc; }
-    // edge branch on the caller's stream
-    if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s)) {
-        join0();
+    if (rc) return rc;
+    if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s))
         return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
-    }
     if (r.fast)
         launch_edge_embed_bf16(r.pk, k, w.geomh, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
                                derp<float>(c, c->edge_embed_b1p), (bf16_t*)w.e, s);
@@ -771,13 +742,12 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
                               g.depth_res_edge_feature > 1 ? derp<float>(c, c->edge_embed[1].wt) : nullptr,
                               g.depth_res_edge_feature > 1 ? rawp(c, c->edge_embed[1].b) : nullptr,
                               g.depth_res_edge_feature, (float*)w.e, s);
-    join0();
     if (io->h0) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h0, s);
     if (io->e0) unpack_e(r, io->e0);
     if (io->stop_after == 1) { HIP_TRY(hipGetLastError()); return RNAMPNN_OK; }
 
     // ---- L x ResMPNN.forward (mpnn.py:283-294), edge update of layer l fused with the message of l+1
-    if (!fused_first) node_pq(r, c->mpnn[0].msg, w.hA, w.pq_m, w.q_m);
+    if (!fused_first) node_pq(r, c->mpnn[0].msg, w.hA, false);
     bool edge_pending = false;                                 // layer l-1's edge update not yet applied
     for (int l = 0; l < L; ++l) {
         mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr);
@@ -788,18 +758,14 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
         const float* gsh = rawp(c, c->mpnn[l].gn_shift);
         if (r.fast && (need_e || need_m)) {
             // the bf16 kernel wrote h + agg; GraphNorm + both [P | Q] projections in one kernel
-            const Mlp2* j0 = need_e ? &c->mpnn[l].edge : &c->mpnn[l + 1].msg;
-            const Mlp2* j1 = (need_e && need_m) ? &c->mpnn[l + 1].msg : nullptr;
-            float* p0 = need_e ? w.pq_e : w.pq_m;
-            bf16_t* q0 = need_e ? w.q_e : w.q_m;
-            launch_node_update(r.pk, w.hB, nullptr, gsc, gsh, t_norm, w.coef, w.hA, j1 ? 2 : 1, derp<bf16_t>(c, j0->pq_img),
-                               derp<float>(c, j0->pq_bp), p0, q0, j1 ? derp<bf16_t>(c, j1->pq_img) : nullptr,
-                               j1 ? derp<float>(c, j1->pq_bp) : nullptr, j1 ? w.pq_m : nullptr, j1 ? w.q_m : nullptr, s);
+            const NodeJob je = need_e ? node_job(c, c->mpnn[l].edge, w.p_e, w.q_e) : NodeJob{};
+            const NodeJob jm = need_m ? node_job(c, c->mpnn[l + 1].msg, w.p_m, w.q_m) : NodeJob{};
+            launch_node_update(r.pk, w.hB, nullptr, gsc, gsh, t_norm, w.coef, w.hA, (need_e && need_m) ? 2 : 1, need_e ? je : jm, jm, s);
         } else {
             // (both kernel families write h + agg)
             launch_graph_norm_packed(r.pk, w.hB, nullptr, w.hA, gsc, gsh, t_norm, s);
-            if (need_e) node_pq(r, c->mpnn[l].edge, w.hA, w.pq_e, w.q_e);
-            if (need_m) node_pq(r, c->mpnn[l + 1].msg, w.hA, w.pq_m, w.q_m);
+            if (need_e) node_pq(r, c->mpnn[l].edge, w.hA, true);
+            if (need_m) node_pq(r, c->mpnn[l + 1].msg, w.hA, false);
         }
         if (io->tap_layer == l + 1) {
             if (io->h_layer) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, io->h_layer, s);
@@ -810,26 +776,12 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
             }
         }
     }
-    // ---- post fusion, raw embedding, readout (rnampnn.py:179-181).  The raw-embedding branch (RawFFN + GraphNorm) depends on
-    // the raw features only: with the fused FFN kernel it runs on the second auxiliary stream beside the small kernels of the
-    // post-fusion attention stack (own output buffers rb0 / rb1) and joins before the read-out
-    const bool ovl_raw = ovl && r.fast && c->raw_chain.ok;
-    float* raw_emb = ovl_raw ? w.rb1 : w.n2;
-    if (ovl_raw) {
-        (void)hipEventRecord(c->fj[2], s); (void)hipStreamWaitEvent(c->aux[1], c->fj[2], 0);
-        r.s = c->aux[1];
-        run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.rb0);
-        launch_graph_norm_packed(r.pk, w.rb0, nullptr, w.rb1, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, r.s);
-        (void)hipEventRecord(c->fj[3], c->aux[1]);
-        r.s = s;
-    }
+    // ---- post fusion, raw embedding, readout (rnampnn.py:179-181)
+    float* raw_emb = w.n2;
     rc = run_bert(r, c->post, w.hA, w.n0);                     // h_post -> n0
-    if (ovl_raw) (void)hipStreamWaitEvent(s, c->fj[3], 0);
     if (rc) return rc;
-    if (!ovl_raw) {
-        run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
-        launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
-    }
+    run_ffn(r, c->raw_chain, c->raw_ffn, w.raw_p, RN_RAWP, w.n1);
+    launch_graph_norm_packed(r.pk, w.n1, nullptr, w.n2, rawp(c, c->rawffn_gn_scale), rawp(c, c->rawffn_gn_shift), t_norm, s);   // raw_emb -> n2
     if (io->h_post) launch_unpack_nodes(r.pk, w.n0, RN_D, RN_D, io->h_post, s);
     if (io->raw_emb) launch_unpack_nodes(r.pk, raw_emb, RN_D, RN_D, io->raw_emb, s);
     if (io->embedding) {
@@ -887,7 +839,7 @@ extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* 
         launch_pack_edges(r.pk, k, e_in, (float*)w.e, s);
     }
     const MpnnLayer& m = c->mpnn[layer];
-    node_pq(r, m.msg, w.hA, w.pq_m, w.q_m);
+    node_pq(r, m.msg, w.hA, false);
     float* msg_p = msg_out ? w.big : nullptr;
     mpnn_step(r, nullptr, &m.msg, w.hA, w.hB, msg_p);
     if (msg_out) launch_unpack_edges(r.pk, k, w.big, nullptr, msg_out, s);
@@ -895,7 +847,7 @@ extern "C" int rnampnn_mpnn_layer(rnampnn_handle h, int32_t layer, const float* 
         launch_graph_norm_packed(r.pk, w.hB, nullptr, w.hA, rawp(c, m.gn_scale), rawp(c, m.gn_shift), t_norm, s);
         if (h_out) launch_unpack_nodes(r.pk, w.hA, RN_D, RN_D, h_out, s);
         if (e_out) {
-            node_pq(r, m.edge, w.hA, w.pq_e, w.q_e);
+            node_pq(r, m.edge, w.hA, true);
             mpnn_step(r, &m.edge, nullptr, w.hA, w.hB, nullptr);
             unpack_e(r, e_out);
         }

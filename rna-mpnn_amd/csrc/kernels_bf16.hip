@@ -22,236 +22,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-static constexpr float kSEPS = 1.0e-6f;
-
-__device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(bf16_t, (__bf16)x); }   // RNE, NaN kept
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ unsigned pack2(float a, float b) {        // one v_cvt_pk_bf16_f32
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float lo_bf(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float hi_bf(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-
-__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef RN_EXP_NOMFMA
-    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
-#endif
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// GELU for the bf16 path: x * sigmoid(x * (c0 + c1 x^2)), coefficients minimax-fitted to the exact
-// erf form (max |err| 2.7e-4 at |x| ~ 2-3, 15-30x below the bf16 rounding of the result there);
-// monotone argument, so no clamp: 7 VALU instructions, 2 of them transcendental.
-// The f32 path and the node-level GEMM epilogues keep erff().
-__device__ __forceinline__ float gelu_fast(float x) {
-#ifdef RN_GELU_ABS      // experiment: exponent x (c0 + c1 |x|): one instruction fewer, max |err| 2.3e-3
-    float p = fmaf(__builtin_fabsf(x), -0.29175830f, -2.1208189f);
-    float ex = __builtin_amdgcn_exp2f(x * p);
-    return x * __builtin_amdgcn_rcpf(1.0f + ex);
-#else
-    float t = x * x;
-    float p = fmaf(t, -0.10012571f, -2.3087657f);          // -log2(e) * (c0 + c1 t), c0 = 1.60031416, c1 = 0.06940179
-    float ex = __builtin_amdgcn_exp2f(x * p);              // exp(-x (c0 + c1 t))
-    return x * __builtin_amdgcn_rcpf(1.0f + ex);
-#endif
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-
-// Packed-f16 activation arithmetic of the fused ResMPNN kernel: the kernel is VALU-issue
-// bound on GELU, and v_pk_*_f16 evaluates two activations per instruction with no transcendental.
-//   GELU(x) = x * Phi(x),  Phi(x) ~ clamp01(0.5 + x * q(min(x^2, S)))   (odd polynomial for Phi - 1/2; the clamp of
-//   x^2 makes the argument monotone, so beyond sqrt(S) the form saturates to exactly 0 / 1)
-// Hidden activations then stay in f16 (11-bit significand, finer than the bf16 they replace) and feed
-// v_mfma_f32_32x32x16_f16; where the result is consumed in f32 (residual, mean) the final x * Phi is a mixed-precision
-// FMA on the f32 accumulator, so only Phi itself is rounded to f16.
-#ifndef RN_PHI_DEG
-#define RN_PHI_DEG 4              // number of coefficients of q
-#endif
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-__device__ __forceinline__ f16x2 cvt_h2(float a, float b) {          // one v_cvt_pk_f16_f32 (RNE)
-    f32x2 v = {a, b};
-    return __builtin_convertvector(v, f16x2);
-}
-__device__ __forceinline__ f16x2 h2(float v) { return f16x2{(_Float16)v, (_Float16)v}; }
-__device__ __forceinline__ f16x2 phi2(f16x2 x) {
-#if RN_PHI_DEG == 4      // max |x Phi - gelu| 3.1e-3 in exact arithmetic
-    f16x2 s = __builtin_elementwise_min(x * x, h2(9.5f));
-    f16x2 q = __builtin_elementwise_fma(s, h2(-0.00017380498f), h2(0.0048129941f));
-    q = __builtin_elementwise_fma(q, s, h2(-0.05394074f));
-    q = __builtin_elementwise_fma(q, s, h2(0.38869277f));
-#else                    // 5 coefficients in s/4 (keeps every coefficient a normal f16): 1.2e-3
-    f16x2 s = __builtin_elementwise_min(x * (x * h2(0.25f)), h2(11.5f * 0.25f));
-    f16x2 q = __builtin_elementwise_fma(s, h2(1.066712254e-05f * 256.f), h2(-0.00041787775f * 64.f));
-    q = __builtin_elementwise_fma(q, s, h2(0.00673485407f * 16.f));
-    q = __builtin_elementwise_fma(q, s, h2(-0.05988154784f * 4.f));
-    q = __builtin_elementwise_fma(q, s, h2(0.39435085475f));
-#endif
-    f16x2 p = __builtin_elementwise_fma(x, q, h2(0.5f));
-    return __builtin_elementwise_min(__builtin_elementwise_max(p, h2(0.f)), h2(1.f));
-}
-__device__ __forceinline__ unsigned gelu_h2(float a, float b) {      // two activations -> packed f16 GELU
-    f16x2 x = cvt_h2(a, b);
-    return __builtin_bit_cast(unsigned, x * phi2(x));
-}
-// Four activations at a time: the two packed chains are independent, so the compiler interleaves them and the
-// one-wait-state hazard between dependent VOP3P instructions (an s_nop 0 = 4 issue cycles each) disappears.
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-__device__ __forceinline__ f16x4 h4(float v) { return f16x4{(_Float16)v, (_Float16)v, (_Float16)v, (_Float16)v}; }
-__device__ __forceinline__ f16x4 cvt_h4(float a, float b, float c, float d) {
-    f32x4 v = {a, b, c, d};
-    return __builtin_convertvector(v, f16x4);
-}
-__device__ __forceinline__ f16x4 phi4(f16x4 x) {
-#if RN_PHI_DEG == 4
-    f16x4 s = __builtin_elementwise_min(x * x, h4(9.5f));
-    f16x4 q = __builtin_elementwise_fma(s, h4(-0.00017380498f), h4(0.0048129941f));
-    q = __builtin_elementwise_fma(q, s, h4(-0.05394074f));
-    q = __builtin_elementwise_fma(q, s, h4(0.38869277f));
-#else
-    f16x4 s = __builtin_elementwise_min(x * (x * h4(0.25f)), h4(11.5f * 0.25f));
-    f16x4 q = __builtin_elementwise_fma(s, h4(1.066712254e-05f * 256.f), h4(-0.00041787775f * 64.f));
-    q = __builtin_elementwise_fma(q, s, h4(0.00673485407f * 16.f));
-    q = __builtin_elementwise_fma(q, s, h4(-0.05988154784f * 4.f));
-    q = __builtin_elementwise_fma(q, s, h4(0.39435085475f));
-#endif
-    f16x4 p = __builtin_elementwise_fma(x, q, h4(0.5f));
-    return __builtin_elementwise_min(__builtin_elementwise_max(p, h4(0.f)), h4(1.f));
-}
-// The two edge kernels work in a SCALED activation domain y = a x, a = 1 / sqrt(9.5) (kGA): then min(x^2, 9.5) / 9.5 = clamp01(y^2) and the
-// clamp is a free output modifier of the multiply - one instruction less per pair of activations (8 -> 7; both kernels are bound by the
-// issue of exactly these instructions).  Phi(x) = clamp01(1/2 + y Q(clamp01(y^2))), Q's coefficients = those of q times 9.5^i / a.  The factor
-// is folded into what feeds the first Linears (P / Q tables, W0 and b0 of the embedding, the biases of the second Linears) and the edge
-// tensor itself is stored scaled (e_hat = a e: e_hat' = e_hat + y Phi(y) needs no rescaling); the message mean, the taps and the stage API
-// divide it out.  phi*s take y.
-static constexpr float kGA = 0.324442842f, kGAi = 3.082207001f;
-#define RN_QS0 1.19803158f
-#define RN_QS1 -1.57943700f
-#define RN_QS2 1.33882663f
-#define RN_QS3 -0.45929830f
-__device__ __forceinline__ f16x4 clamp01h(f16x4 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, h4(0.f)), h4(1.f)); }
-__device__ __forceinline__ f16x2 clamp01h(f16x2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, h2(0.f)), h2(1.f)); }
-__device__ __forceinline__ f16x4 phi4s(f16x4 y) {
-    const f16x4 s = clamp01h(y * y);
-    f16x4 q = __builtin_elementwise_fma(s, h4(RN_QS3), h4(RN_QS2));
-    q = __builtin_elementwise_fma(q, s, h4(RN_QS1));
-    q = __builtin_elementwise_fma(q, s, h4(RN_QS0));
-    return clamp01h(__builtin_elementwise_fma(y, q, h4(0.5f)));
-}
-__device__ __forceinline__ f16x2 phi2s(f16x2 y) {
-    const f16x2 s = clamp01h(y * y);
-    f16x2 q = __builtin_elementwise_fma(s, h2(RN_QS3), h2(RN_QS2));
-    q = __builtin_elementwise_fma(q, s, h2(RN_QS1));
-    q = __builtin_elementwise_fma(q, s, h2(RN_QS0));
-    return clamp01h(__builtin_elementwise_fma(y, q, h2(0.5f)));
-}
-__device__ __forceinline__ f16x2 lo2(f16x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
-__device__ __forceinline__ f16x2 hi2(f16x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
-// Copy a 64 KiB fragment image (4096 x 16 B) into LDS with NT threads: all of a thread's loads are issued before its
-// first LDS write (a plain copy loop compiles to load -> wait -> write per iteration, i.e. one L2 round trip each).
-template <int NT>
-__device__ __forceinline__ void stage_image(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
-    constexpr int PER = (4096 + NT - 1) / NT;
-    constexpr int BATCH = PER < 8 ? PER : 8;
-    constexpr bool EXACT = 4096 % NT == 0;
-#pragma unroll
-    for (int b0 = 0; b0 < PER; b0 += BATCH) {
-        u32x4 t[BATCH];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) if (b0 + i < PER) t[i] = src[EXACT ? tid + (b0 + i) * NT : min(tid + (b0 + i) * NT, 4095)];
-#pragma unroll
-        for (int i = 0; i < BATCH; ++i) if (b0 + i < PER && (EXACT || tid + (b0 + i) * NT < 4096)) dst[tid + (b0 + i) * NT] = t[i];
-    }
-}
-// The same copy by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, every piece of a thread in flight at once; a wave's
-// piece is 1 KiB: wave-uniform LDS base, the DMA adds lane * 16).  The caller waits with s_waitcnt vmcnt(0) + a workgroup barrier
-// before the first read (the compiler does not know these loads write LDS).  TOTAL: 16-byte units, whole waves per piece.
-#ifndef RN_NO_DMA_STAGE
-#define RN_DMA_STAGE 1
-#endif
-template <int NT, int TOTAL = 4096>
-__device__ __forceinline__ void stage_image_dma(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
-    static_assert(TOTAL % 64 == 0 && NT % 64 == 0, "whole waves per DMA piece");
-    constexpr int PER = (TOTAL + NT - 1) / NT;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-        if (TOTAL % NT == 0 || tid + i * NT < TOTAL)       // (wave-uniform: NT and TOTAL are multiples of 64)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + tid + i * NT),
-                                             (__attribute__((address_space(3))) void*)(dst + (tid & ~63) + i * NT), 16, 0, 0);
-}
-__device__ __forceinline__ void dma_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// x as a (hi, lo) pair of bf16 in one word (hi in the low half): x = hi + lo to ~16 bits.  Operand of the k = 2 MFMAs that
-// add a per-row constant (bias, P row) to an accumulator tile.
-__device__ __forceinline__ unsigned split_word(float x) {
-    const unsigned hi = pack2(x, 0.f) & 0xffffu;
-    return hi | (pack2(x - __uint_as_float(hi << 16), 0.f) << 16);
-}
-// a * f16(lo / hi half of hp) + c in one mixed-precision FMA (f32 result)
-__device__ __forceinline__ float fma_mix_lo(float a, f16x2 hp, float c) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(hp), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float fma_mix_hi(float a, f16x2 hp, float c) {
-    float d;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(a), "v"(hp), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef RN_EXP_NOMFMA
-    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
-#endif
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// Storage format of the per-edge tensor e of this path (fragment-major, see efrag_ptr): f16 of a e.  |a e| stays far inside the f16 range,
-// the 11 mantissa bits beat bf16's 8, and - the reason - the residual update e <- e + GELU(.) of the fused kernel becomes ONE packed fma on
-// the fragment words as loaded (bf16 storage cost an unpack, an f32 mixed fma and a repack per element: 10 vector instructions per four
-// elements against 2, 128 of the ~1,460 a block issues), and the products e . Wc run as f16 MFMAs on the words as loaded.
-// RN_E_F16=0 builds the bf16-storage form (A/B).
-#ifndef RN_E_F16
-#define RN_E_F16 1
-#endif
-__device__ __forceinline__ bf16_t e_enc(float x) { return RN_E_F16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f2bf(x); }
-__device__ __forceinline__ float e_dec(bf16_t v) { return RN_E_F16 ? (float)__builtin_bit_cast(_Float16, v) : bf2f(v); }
-__device__ __forceinline__ f32x16 mfma_e(u32x4 a, u32x4 b, f32x16 c) { return RN_E_F16 ? mfma32h(a, b, c) : mfma32(a, b, c); }
-// Storage format of the per-residue P tables (k_node_update -> fused kernel): f16 of a P, one halfword per entry in the SAME entry order as the
-// (hi, lo) bf16 words of rounds 1-2 (entry 32 mb + m <-> accumulator row m of channel block mb).  The injection MFMA then is an f16 product of
-// (P, 0) against (1, 1); 11 significand bits against the 8 of the gathered Q rows beside it.  Halves the P bytes k_node_update writes (it is
-// HBM-bound on its table writes) and the fused kernel reads.  RN_P_F16=0 builds the word form (A/B).
-#ifndef RN_P_F16
-#define RN_P_F16 1
-#endif
-__device__ __forceinline__ unsigned p_pack2(float a, float b) {       // two P entries -> one word of two f16
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-
-// channel held by accumulator row m of a 32-row block when the output order is "natural per lane":
-// lane half h = (m>>2)&1, register i = (m&3) + 4*(m>>3)  ->  channel 32*blk + 16*h + i
-__host__ __device__ __forceinline__ int ch_nat(int blk, int m) { return 32 * blk + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
-// ... when the output order must equal the e B-fragment layout (lane half h holds channels
-// 32*blk + 8h + {0..7} and 32*blk + 16 + 8h + {0..7})
-__host__ __device__ __forceinline__ int ch_efrag(int blk, int m) {
-    int h = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
-    return i < 8 ? 32 * blk + 8 * h + i : 32 * blk + 16 + 8 * h + (i - 8);
-}
+#include "bf16_dev.h"
 
 // ------------------------------------------------------------------------------------------
 // weight preparation
@@ -466,10 +237,10 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
 #else
 #define STAMP(var) do { } while (0)
 #endif
-struct NodeTabs {             // per-residue parts of the first Linears (k_node_update outputs)
-    const unsigned* p_e;      // [N+1][128] words: P = h.Wa_e^T + b1_e as (hi, lo) bf16 pairs, word 32mb + m <-> channel ch_nat(mb, m)
-    const bf16_t* q_e;        // [N+1][128] bf16  h.Wb_e^T         (row N = zeros)
-    const unsigned* p_m;
+struct NodeTabs {             // per-residue parts of the first Linears (k_node_update outputs): f16 of a P / a Q, natural channel order
+    const bf16_t* p_e;        // [N+1][128] f16  P = h.Wa_e^T + b1_e
+    const bf16_t* q_e;        // [N+1][128] f16  h.Wb_e^T         (row N = zeros)
+    const bf16_t* p_m;
     const bf16_t* q_m;
     const float* h_res;       // [N][128] f32 or null: the residue's h, added to the mean so that the launch writes h + agg (mpnn.py:222): the
                               // statistics and update kernels behind it then read ONE node tensor instead of two
@@ -551,13 +322,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         for (int s = 0; s < 8; ++s) ef[s] = efrag_ptr(e, b0, lane)[64 * s];
 #endif
         if (!SMALLK) {
-#if RN_P_F16
-            if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b0 * RN_D)[lane];
-            if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b0 * RN_D)[lane];
-#else
-            if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b0 * RN_D + 2 * lane);
-            if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b0 * RN_D + 2 * lane);
-#endif
+            if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(tab.p_e + (size_t)b0 * RN_D)[lane];
+            if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(tab.p_m + (size_t)b0 * RN_D)[lane];
             if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b0 * RN_D + 2 * lane);
         }
     }
@@ -577,14 +343,14 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         u32x4 pv;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            pv[t] = (sp == sp_r && jstar == 2 * t ? 0x3F80u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3F800000u : 0u);
+            pv[t] = (sp == sp_r && jstar == 2 * t ? 0x3C00u : 0u) | (sp == sp_r && jstar == 2 * t + 1 ? 0x3C000000u : 0u);      // f16 ones
         lds_perm[tid] = pv;
         if (EDGE1) {
             // rows in ch_efrag order: row (h' = sp_r, i = c16) holds channel 16 (i >> 3) + 8 h' + (i & 7) of its 32-block
             const bool hit = sp == (c16 >> 3) && hh == sp_r;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                pv[t] = (hit && (c16 & 7) == 2 * t ? 0x3F80u : 0u) | (hit && (c16 & 7) == 2 * t + 1 ? 0x3F800000u : 0u);
+                pv[t] = (hit && (c16 & 7) == 2 * t ? 0x3C00u : 0u) | (hit && (c16 & 7) == 2 * t + 1 ? 0x3C000000u : 0u);
             lds_perm[128 + tid] = pv;
         }
     }
@@ -640,72 +406,44 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     };
     auto load_p = [&](int b) {                         // !SMALLK: the residue's P words (coalesced 512 B rows), requested early ...
         if (SMALLK) return;
-#if RN_P_F16
-        if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b * RN_D)[lane];
-        if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b * RN_D)[lane];
-#else
-        if (DO_EDGE) pn_e = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + 2 * lane);
-        if (DO_MSG) pn_m = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + 2 * lane);
-#endif
+        if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(tab.p_e + (size_t)b * RN_D)[lane];
+        if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(tab.p_m + (size_t)b * RN_D)[lane];
         if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b * RN_D + 2 * lane);
     };
     auto stage_p = [&]() {                             // ... through the wave's LDS slot ...
         if (SMALLK) return;
-#if RN_P_F16
-        if (DO_EDGE) lds_p[lane] = pn_e[0];                  // 128 halfwords per MLP
+        if (DO_EDGE) lds_p[lane] = pn_e[0];                  // 128 halfwords per MLP, natural channel order
         if (DO_MSG) lds_p[128 + lane] = pn_m[0];
-#else
-        if (DO_EDGE) *reinterpret_cast<u32x2*>(lds_p + 2 * lane) = pn_e;
-        if (DO_MSG) *reinterpret_cast<u32x2*>(lds_p + 128 + 2 * lane) = pn_m;
-#endif
         if (DO_MSG) *reinterpret_cast<f32x2*>(lds_p + 256 + 2 * lane) = hn;
     };
     auto fetch_p = [&]() {                             // ... back as this lane's four words per MLP
         if (SMALLK) return;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
-#if RN_P_F16
-            if (DO_EDGE) pwe[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p)[32 * mb + r] : 0u;           // (P, 0): k = 1 carries nothing
-            if (DO_MSG) pwm[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p + 128)[32 * mb + r] : 0u;
-#else
-            if (DO_EDGE) pwe[mb] = h == 0 ? lds_p[32 * mb + r] : 0u;
-            if (DO_MSG) pwm[mb] = h == 0 ? lds_p[128 + 32 * mb + r] : 0u;
-#endif
+            // accumulator row r of channel block mb holds channel ch_nat(mb, r) (EDGE1's one edge Linear: ch_efrag); (P, 0): k = 1 carries nothing
+            if (DO_EDGE) pwe[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p)[EDGE1 ? ch_efrag(mb, r) : ch_nat(mb, r)] : 0u;
+            if (DO_MSG) pwm[mb] = h == 0 ? (unsigned)reinterpret_cast<const bf16_t*>(lds_p + 128)[ch_nat(mb, r)] : 0u;
         }
     };
     // ---- one MFMA of chain c (compile-time c, i), accumulating in T
     //   first Linears  (11): [P words x ones(real edges)] [W . e, k-steps 0..7] [routing x Q, 2]
     //   second Linears ( 9): [bias words x ones]          [W . hidden, k-steps 0..7]
     unsigned onesb = 0u;                               // ones column of this block's real edges (B operand, k = 0, 1)
-    auto inject_p = [&](f32x16& T, const unsigned* ptab, unsigned pw, int mb) {
+    auto inject_p = [&](f32x16& T, const bf16_t* ptab, unsigned pw, int mb, bool efr) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if RN_P_F16
         if (!SMALLK) { T = mfma32h(u32x4{pw, 0u, 0u, 0u}, u32x4{onesb ? 0x3C003C00u : 0u, 0u, 0u, 0u}, z); return; }      // f16 ones where the bf16 ones column has them
+        // several residues per block: k-pair 4h + jj of group g carries residue g + 4h + jj against the indicator of its edges
         T = z;
+        const int chn = efr ? ch_efrag(mb, r) : ch_nat(mb, r);
         for (int g = 0; g < npb; g += 8) {
             u32x4 aw, bwv;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int qq = g + 4 * h + jj, node = blk * npb + qq;
-                aw[jj] = (qq < npb && node < ntot) ? (unsigned)reinterpret_cast<const bf16_t*>(ptab)[(size_t)node * RN_D + 32 * mb + r] : 0u;
+                aw[jj] = (qq < npb && node < ntot) ? (unsigned)ptab[(size_t)node * RN_D + chn] : 0u;
                 bwv[jj] = (j >= 0 && q0 == qq) ? 0x3C003C00u : 0u;
             }
             T = mfma32h(aw, bwv, T);
-        }
-        return;
-#endif
-        if (!SMALLK) { T = mfma32(u32x4{pw, 0u, 0u, 0u}, u32x4{onesb, 0u, 0u, 0u}, z); return; }
-        // several residues per block: k-pair 4h + jj of group g carries residue g + 4h + jj against the indicator of its edges
-        T = z;
-        for (int g = 0; g < npb; g += 8) {
-            u32x4 aw, bwv;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int qq = g + 4 * h + jj, node = blk * npb + qq;
-                aw[jj] = (qq < npb && node < ntot) ? ptab[(size_t)node * RN_D + 32 * mb + r] : 0u;
-                bwv[jj] = (j >= 0 && q0 == qq) ? 0x3F803F80u : 0u;
-            }
-            T = mfma32(aw, bwv, T);
         }
     };
     auto chain_step = [&](auto cc, auto ii, f32x16& T) {
@@ -717,8 +455,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         if constexpr (i > 8) return;
 #endif
         if constexpr (i == 0) {
-            if constexpr (kind == 0) inject_p(T, tab.p_e, pwe[cb], cb);
-            else if constexpr (kind == 2) inject_p(T, tab.p_m, pwm[cb], cb);
+            if constexpr (kind == 0) inject_p(T, tab.p_e, pwe[cb], cb, EDGE1);
+            else if constexpr (kind == 2) inject_p(T, tab.p_m, pwm[cb], cb, false);
             else if constexpr (kind == 1) T = mfma32(u32x4{bwn, 0u, 0u, 0u}, u32x4{onesb, 0u, 0u, 0u}, z);
             else T = mfma32(ones_a, u32x4{bwn, 0u, 0u, 0u}, z);
         } else if constexpr (i <= 8) {
@@ -735,8 +473,8 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                 else if constexpr (kn == 3) bwn = lds_bwm[(cn & 3) * 64 + lane];
             }
         } else {
-            if constexpr (EDGE1 && kind == 0) T = mfma32(i == 9 ? perm0e : perm1e, q[2 * cb + (i - 9)], T);
-            else T = mfma32(i == 9 ? perm0 : perm1, q[2 * cb + (i - 9)], T);
+            if constexpr (EDGE1 && kind == 0) T = mfma32h(i == 9 ? perm0e : perm1e, q[2 * cb + (i - 9)], T);      // (the Q tables are f16)
+            else T = mfma32h(i == 9 ? perm0 : perm1, q[2 * cb + (i - 9)], T);
         }
     };
     // ---- the epilogue of chain c in GRANULES of ~8 vector instructions (one rides behind each MFMA of the next chain).
@@ -978,274 +716,15 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #undef RN_FRAG
 }
 
-// ------------------------------------------------------------------------------------------
-// The same fused ResMPNN step on 16-EDGE tiles with v_mfma_f32_16x16x32 (round 3) - an EXPERIMENT, correct (every parity test passes with
-// RNAMPNN_MPNN16=1) and slower than the 32-edge kernel (212 - 232 us per launch against 163 us at C2), kept as the measured answer to "why not
-// four waves per SIMD".  profiles/r03_pmc_sq_k_mpnn16_bf16_experiment.txt: the SIMDs issue 59.2 M vector + 8.8 M matrix + 10.3 M LDS
-// instructions per launch against 44.8 M + 4.9 M + 4.8 M: a 16x16x32 MFMA holds the vector issue for 8 of its 16 cycles (a 32x32x16 for 8 of
-// its 32), every weight fragment is read from LDS per 16 edges instead of per 32, and the per-tile bookkeeping (accumulator init, masks)
-// repeats twice as often.  Issue slots, not occupancy, bound this computation: ~340 K issue cycles per SIMD of the 387 K the launch lasts
-// (88 %) - the 32-edge kernel needs 232 K and uses 77 % of its 300 K.  Why a second kernel was tried: the 32-edge version keeps ~248
-// registers live per wave (e fragments 32, hidden fragments 32, gathered Q rows 32, two 32x32 accumulator tiles 32, weight ring 32), i.e.
-// two waves per SIMD, and its waves spend 40 % of their cycles waiting to issue behind each other's MFMAs and activation arithmetic.  At
-// 16 edges per tile every per-edge quantity halves (e 16, hidden 16, Q 16, tiles 4 + 4): four waves per SIMD, and the matrix / vector work
-// of different waves overlaps by hardware scheduling instead of by a hand-placed interleave.  A wave owns one residue (32 slots) and walks
-// it as two halves, so the mean over the neighbourhood stays in the wave.
-//   Lane (c, g) = (lane & 15, lane >> 4): edge c of the half on the MFMA columns, k-slice g of a 32-deep k-step.
-//   e fragment of k-step s' (channels 32 s' + 8 g .. + 8 of edge c): the SAME bytes as in the 32-edge kernel - HBM layout unchanged -
-//     at 16-byte unit (2 s' + (g >> 1)) * 64 + 32 (g & 1) + 16 half + c of the block.
-//   First Linears, transposed: tile mb (16 hidden channels 16 mb .. + 16) = P row (accumulator INIT from the wave's LDS slot: no injection
-//     MFMA) + 4 MFMAs over e + 1 routing MFMA for the gathered Q row; GELU; the two tiles 2 s'', 2 s'' + 1 packed to f16 are the fragment of
-//     k-step s'' of the second Linear (element j of slice g <-> hidden channel 16 (2 s'' + (j >> 2)) + 4 g + (j & 3): the second Linear's
-//     images are built in that k order).
-//   Edge second Linear, transposed, rows of tile 2 s' + u <-> channels 32 s' + 8 (m >> 2) + 4 u + (m & 3): a lane's 4 accumulators are
-//     elements 4 u .. 4 u + 3 of the e fragment it loaded - residual add and 16-byte store in place.  Absent slots compute on zeros / P and are
-//     stored back as zeros (one select per fragment): the "absent rows stay zero" invariant of the layout holds.
-//   Message second Linear, un-transposed (A = hidden fragments, B = weights): edges on the accumulator rows; rows of absent edges are
-//     zeroed before the activation (GELU(0) = 0), the sum over rows is 4 in-lane FMAs + one cross-slice reduction per residue.
-// LDS: [4 x 32 KiB images: E1 | E2 | M1 | M2][per wave: P_e, P_m, (unused) 3 x 512 B][bias E2 (row order) | bias M2 512 B each][2 routing fragments].
-#define RN16_WAVES 16
-#define RN16_LDS (131072 + RN16_WAVES * 1536 + 1024 + 2048)
-__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// hidden channel carried by element j of k-slice g in k-step s of a second Linear; row -> channel of the edge MLP's second Linear
-__host__ __device__ __forceinline__ int hid16(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
-__host__ __device__ __forceinline__ int row16_e(int mb, int m) { return 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3); }
-// images of one depth-2 MLP for the 16-edge kernel: [lin 0][mb][s][lane][8] first Linear's e part (bf16), [lin 1][mb][s][lane][8] second
-// Linear (f16; edge MLP: rows in row16_e order; message MLP: B operand, natural columns); b2p: the second bias in that row order
-__global__ void k_build_mlp16_image(const float* __restrict__ wc, int ld_wc, const float* __restrict__ w2, int ld_w2,
-                                    const float* __restrict__ b2, int is_edge, bf16_t* __restrict__ img, float* __restrict__ b2p) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id < 2 * 32 * 64 * 8) {
-        const int j = id & 7, lane = (id >> 3) & 63, f = (id >> 9) & 31, which = id >> 14;
-        const int m = lane & 15, g = lane >> 4, mb = f >> 2, sft = f & 3;
-        if (which == 0) img[id] = e_enc(wc[(size_t)(16 * mb + m) * ld_wc + 32 * sft + 8 * g + j]);
-        else img[id] = __builtin_bit_cast(bf16_t, (_Float16)w2[(size_t)(is_edge ? row16_e(mb, m) : 16 * mb + m) * ld_w2 + hid16(sft, g, j)]);
-    }
-    if (id < 128) b2p[id] = kGA * b2[is_edge ? row16_e(id >> 4, id & 15) : id];      // (scaled activation domain, as the 32-edge kernel)
-}
-void launch_build_mlp16_image(const float* wc, int ld_wc, const float* w2, int ld_w2, const float* b2, int is_edge, bf16_t* img, float* b2p,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(k_build_mlp16_image, dim3(2 * 32 * 64 * 8 / 256), dim3(256), 0, s, wc, ld_wc, w2, ld_w2, b2, is_edge, img, b2p);
-}
-
-// (a scheduling fence per tile: without it the compiler hoists the LDS weight reads of many tiles and spills 168 registers)
-#define RN16_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <bool DO_EDGE>
-__global__ void __launch_bounds__(RN16_WAVES * 64) k_mpnn16_bf16(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e, NodeTabs tab,
-        const bf16_t* __restrict__ img_e, const float* __restrict__ b2e, const bf16_t* __restrict__ img_m, const float* __restrict__ b2m,
-        float* __restrict__ agg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NW = RN16_WAVES;
-    u32x4* img = reinterpret_cast<u32x4*>(smem);                                 // [lin][mb][s][lane]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    float* slot = reinterpret_cast<float*>(smem + 131072) + wave * 384;           // [P_e 128][P_m 128][spare 128]
-    float* lds_b2e = reinterpret_cast<float*>(smem + 131072 + NW * 1536);
-    float* lds_b2m = lds_b2e + 128;
-    u32x4* lds_perm = reinterpret_cast<u32x4*>(lds_b2m + 128);                    // [u 0..1][lane]
-    const int ntot = pk.cu[pk.B];
-    if (DO_EDGE) stage_image_dma<NW * 64>(img, reinterpret_cast<const u32x4*>(img_e), tid);
-    stage_image_dma<NW * 64>(img + 4096, reinterpret_cast<const u32x4*>(img_m), tid);
-    if (tid < 128) lds_b2e[tid] = DO_EDGE ? b2e[tid] : 0.f;
-    else if (tid < 256) lds_b2m[tid - 128] = b2m[tid - 128];
-    else if (tid < 384) {
-        // routing fragment u: row m of a tile with parity u holds channel 16 u + m of its 32-channel k-step; lane (m, gg) element j is k = 8 gg + j
-        const int t = tid - 256, u = t >> 6, ll = t & 63, m = ll & 15, gg = ll >> 4;
-        const int kk = 16 * u + m;
-        u32x4 pv;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            pv[w] = ((kk >> 3) == gg && (kk & 7) == 2 * w ? 0x3F80u : 0u) | ((kk >> 3) == gg && (kk & 7) == 2 * w + 1 ? 0x3F800000u : 0u);
-        lds_perm[t] = pv;
-    }
-    dma_landed();
-    __syncthreads();
-    const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
-    int blk, blk_end, stride;
-    if ((gridDim.x & 7) == 0) {
-        const int chunk = (ntot + 7) >> 3, x = blockIdx.x & 7;
-        blk_end = min(ntot, (x + 1) * chunk);
-        stride = (gridDim.x >> 3) * NW;
-        blk = x * chunk + (blockIdx.x >> 3) * NW + wave;
-    } else {
-        blk_end = ntot; stride = gridDim.x * NW; blk = blockIdx.x * NW + wave;
-    }
-    const int zero_row = pk.Nmax;
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    if (blk >= blk_end) return;
-    // Unit = (residue, half).  Everything a unit needs from HBM is requested while the previous unit's last phase (message Linear 2) runs:
-    // its e fragments and Q rows reuse the registers that phase no longer reads, the neighbour index one unit earlier still.
-    auto slot_of = [&](int b, int half) { return 16 * half + c; };
-    auto load_j = [&](int b, int half) -> int {
-        const int sl = 16 * half + c;
-        return (b < blk_end && sl < k) ? nbr[(size_t)b * k + sl] : -1;
-    };
-    auto e_ptr = [&](int b, int half) { return reinterpret_cast<u32x4*>(e) + (size_t)b * 512 + 32 * (g & 1) + 16 * half + c; };
-    auto qrow_of = [&](int j) { return j >= 0 ? (j > zero_row ? zero_row : j) : zero_row; };
-    auto stage_p = [&](int b) {       // the residue's P rows -> f32 in the wave's slot (word w <-> channel ch_nat(w >> 5, w & 31); value = hi + lo)
-        const int w0 = 2 * lane, ch0 = ch_nat(w0 >> 5, w0 & 31), ch1 = ch_nat((w0 + 1) >> 5, (w0 + 1) & 31);
-#if RN_P_F16
-        if (DO_EDGE) {
-            const f16x2 pw = __builtin_bit_cast(f16x2, reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_e) + (size_t)b * RN_D)[lane]);
-            slot[ch0] = (float)pw[0]; slot[ch1] = (float)pw[1];
-        }
-        const f16x2 pm = __builtin_bit_cast(f16x2, reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(tab.p_m) + (size_t)b * RN_D)[lane]);
-        slot[128 + ch0] = (float)pm[0]; slot[128 + ch1] = (float)pm[1];
-#else
-        if (DO_EDGE) {
-            const u32x2 pw = *reinterpret_cast<const u32x2*>(tab.p_e + (size_t)b * RN_D + w0);
-            slot[ch0] = lo_bf(pw[0]) + hi_bf(pw[0]);
-            slot[ch1] = lo_bf(pw[1]) + hi_bf(pw[1]);
-        }
-        const u32x2 pm = *reinterpret_cast<const u32x2*>(tab.p_m + (size_t)b * RN_D + w0);
-        slot[128 + ch0] = lo_bf(pm[0]) + hi_bf(pm[0]);
-        slot[128 + ch1] = lo_bf(pm[1]) + hi_bf(pm[1]);
-#endif
-    };
-    u32x4 ef[4], q[4], hbf[4];
-    int j = load_j(blk, 0);
-    int jn = load_j(blk, 1);
-    {
-        u32x4* ep0 = e_ptr(blk, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ef[s] = ep0[(2 * s + (g >> 1)) * 64];
-        const int qr = qrow_of(j);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>((DO_EDGE ? tab.q_e : tab.q_m) + (size_t)qr * RN_D + 32 * s + 8 * g);
-    }
-    stage_p(blk);
-    float sums[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // this lane's partial of the message sum, channel 16 nb + c
-    int cnt = 0, half = 0;
-    while (true) {
-        const bool valid = j >= 0;
-        const unsigned mask16 = (unsigned)(__ballot(valid) & 0xffffull);          // bit r: edge r of this half exists (lanes g == 0)
-        cnt += __popc(mask16);
-        float vf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vf[i] = (float)((mask16 >> (4 * g + i)) & 1u);
-        u32x4* ep = e_ptr(blk, half);
-        // the unit after the next one: only its neighbour index is requested here
-        const int nblk = half ? blk + stride : blk, nhalf = half ^ 1;               // next unit
-        const int nnblk = nhalf ? nblk + stride : nblk;                             // the one after it (half = nhalf ^ 1)
-        const int jnn = load_j(nnblk, nhalf ^ 1);
-        if (DO_EDGE) {
-            // ---- edge Linear 1
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                f32x4 T = *reinterpret_cast<const f32x4*>(slot + 16 * mb + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) T = RN_E_F16 ? mfma16h(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T) : mfma16(img[((0 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
-                T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
-                const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
-                const f16x4 gv = x * phi4s(x);
-                hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
-                hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
-                RN16_FENCE();
-            }
-            // the message MLP's Q rows are requested now (q is free)
-            {
-                const int qr = qrow_of(j);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>(tab.q_m + (size_t)qr * RN_D + 32 * s + 8 * g);
-            }
-            // ---- edge Linear 2 + residual: tile 2 s + u <-> elements 4 u .. 4 u + 3 of ef[s]
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                f32x4 T = *reinterpret_cast<const f32x4*>(lds_b2e + 16 * mb + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) T = mfma16h(img[((1 * 8 + mb) * 4 + s) * 64 + lane], hbf[s], T);
-                const f16x4 xq = cvt_h4(T[0], T[1], T[2], T[3]);
-                const f16x4 ph = phi4s(xq);
-                const int sp = mb >> 1, u = mb & 1;
-                const unsigned o0 = ef[sp][2 * u], o1 = ef[sp][2 * u + 1];
-#if RN_E_F16
-                ef[sp][2 * u] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(xq), lo2(ph), __builtin_bit_cast(f16x2, o0)));
-                ef[sp][2 * u + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(xq), hi2(ph), __builtin_bit_cast(f16x2, o1)));
-#else
-                ef[sp][2 * u] = pack2(fma_mix_lo(T[0], lo2(ph), lo_bf(o0)), fma_mix_hi(T[1], lo2(ph), hi_bf(o0)));
-                ef[sp][2 * u + 1] = pack2(fma_mix_lo(T[2], hi2(ph), lo_bf(o1)), fma_mix_hi(T[3], hi2(ph), hi_bf(o1)));
-#endif
-                if (u == 1) {
-                    if (!valid) ef[sp] = u32x4{0u, 0u, 0u, 0u};              // absent slots stay zero rows
-                    ep[(2 * sp + (g >> 1)) * 64] = ef[sp];
-                }
-                RN16_FENCE();
-            }
-        }
-        // ---- message Linear 1
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            f32x4 T = *reinterpret_cast<const f32x4*>(slot + 128 + 16 * mb + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) T = RN_E_F16 ? mfma16h(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T) : mfma16(img[((2 * 8 + mb) * 4 + s) * 64 + lane], ef[s], T);
-            T = mfma16((mb & 1) ? perm1 : perm0, q[mb >> 1], T);
-            const f16x4 x = cvt_h4(T[0], T[1], T[2], T[3]);
-            const f16x4 gv = x * phi4s(x);
-            hbf[mb >> 1][2 * (mb & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
-            hbf[mb >> 1][2 * (mb & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
-            RN16_FENCE();
-        }
-        // ---- requests of the next unit: ef and q are dead from here on, the slot after this half's last P read when the block changes
-        const bool has_next = nblk < blk_end;
-        if (has_next) {
-            u32x4* epn = e_ptr(nblk, nhalf);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) ef[s] = epn[(2 * s + (g >> 1)) * 64];
-            const int qr = qrow_of(jn);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) q[s] = *reinterpret_cast<const u32x4*>((DO_EDGE ? tab.q_e : tab.q_m) + (size_t)qr * RN_D + 32 * s + 8 * g);
-            if (half) stage_p(nblk);
-        }
-        RN16_FENCE();
-        // ---- message Linear 2, un-transposed: rows = edges 4 g + i of this half, column = channel 16 nb + c
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-            const float bv = lds_b2m[16 * nb + c];
-            f32x4 T = {bv, bv, bv, bv};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) T = mfma16h(hbf[s], img[((3 * 8 + nb) * 4 + s) * 64 + lane], T);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) T[i] *= vf[i];                        // rows of absent edges: GELU(0) = 0
-            const f16x4 ph = phi4s(cvt_h4(T[0], T[1], T[2], T[3]));
-            float sacc = sums[nb];
-            sacc = fma_mix_lo(T[0], lo2(ph), sacc);
-            sacc = fma_mix_hi(T[1], lo2(ph), sacc);
-            sacc = fma_mix_lo(T[2], hi2(ph), sacc);
-            sacc = fma_mix_hi(T[3], hi2(ph), sacc);
-            sums[nb] = sacc;
-            RN16_FENCE();
-        }
-        if (half) {
-            // ---- mean over the residue's edges (+ its own h): fold the four k-slices, lanes g == 0 write
-            const float inv = cnt > 0 ? kGAi * __builtin_amdgcn_rcpf((float)cnt) : 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                float t = sums[nb];
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);
-                if (g == 0) {
-                    const size_t o = (size_t)blk * RN_D + 16 * nb + c;
-                    agg[o] = fmaf(t, inv, tab.h_res ? tab.h_res[o] : 0.f);
-                }
-                sums[nb] = 0.f;
-            }
-            cnt = 0;
-        }
-        if (!has_next) break;
-        blk = nblk; half = nhalf;
-        j = jn; jn = jnn;
-    }
-}
-
 static int num_cus() { return rn_num_cus(); }
 
 void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, const int* nbr, bf16_t* e,
-                      const float* p_e, const bf16_t* q_e, const float* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
+                      const bf16_t* p_e, const bf16_t* q_e, const bf16_t* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
                       float* agg, float* msg_out, bool edge1, const float* h_res, hipStream_t s) {
+    if (resmpnn_covers(k, edge1, msg_out != nullptr)) {
+        launch_resmpnn_bf16(pk, k, do_edge, do_msg, nbr, e, p_e, q_e, p_m, q_m, we, wm, agg, h_res, s);
+        return;
+    }
     const int npb = k > 16 ? 1 : 32 / k;
     const int max_blocks = (pk.Nmax + npb - 1) / npb;
     int grid = (max_blocks + RN_MPNN_WAVES - 1) / RN_MPNN_WAVES;
@@ -1253,7 +732,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
     size_t lds = RN_MPNN_LDS;
-    NodeTabs tab{reinterpret_cast<const unsigned*>(p_e), q_e, reinterpret_cast<const unsigned*>(p_m), q_m, h_res, nullptr};
+    NodeTabs tab{p_e, q_e, p_m, q_m, h_res, nullptr};
 #ifdef RN_STAMPS
     static unsigned long long* dbg = nullptr;
     if (!dbg) (void)hipMalloc((void**)&dbg, 64);
@@ -1261,22 +740,6 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     tab.dbg = dbg;
 #endif
     const bool smallk = k <= 16, mo = msg_out != nullptr;
-    // opt-in (RNAMPNN_MPNN16=1, read per call so that a test can switch it): measured SLOWER on C2 (212 - 232 us per launch against 163 us), see the
-    // kernel's header and DESIGN.md section 4
-    const char* ev16 = getenv("RNAMPNN_MPNN16");
-    const int use16 = ev16 ? atoi(ev16) : 0;
-    if (use16 && !smallk && !mo && !edge1 && do_msg && wm.img16 && (!do_edge || we.img16)) {      // 16-edge tiles, four waves per SIMD
-        int g16 = (max_blocks + RN16_WAVES - 1) / RN16_WAVES;
-        if (g16 >= 8) g16 = (g16 + 7) & ~7;
-        if (g16 > num_cus()) g16 = num_cus();
-        if (g16 < 1) g16 = 1;
-        static DevAttr a0, a1;
-        ensure_dyn_lds((const void*)k_mpnn16_bf16<true>, RN16_LDS, a0);
-        ensure_dyn_lds((const void*)k_mpnn16_bf16<false>, RN16_LDS, a1);
-        if (do_edge) hipLaunchKernelGGL(k_mpnn16_bf16<true>, dim3(g16), dim3(RN16_WAVES * 64), RN16_LDS, s, pk, k, nbr, e, tab, we.img16, we.b2p16, wm.img16, wm.b2p16, agg);
-        else hipLaunchKernelGGL(k_mpnn16_bf16<false>, dim3(g16), dim3(RN16_WAVES * 64), RN16_LDS, s, pk, k, nbr, e, tab, we.img16, we.b2p16, wm.img16, wm.b2p16, agg);
-        return;
-    }
 #define RN_LAUNCH(E, M, S, O, E1)                                                                              \
     do {                                                                                                       \
         static DevAttr attr;                                                                                   \
@@ -1960,7 +1423,7 @@ __device__ unsigned long long nu_dbg[3][8];
 #else
 #define NU_STAMP(i) do { } while (0)
 #endif
-struct PqJob { const bf16_t* img; const float* bias; float* p; bf16_t* q; };   // img: [8 ob][8 ks][64][8]; ob<4 -> P rows (stored as split-bf16 words), >=4 -> Q rows
+typedef NodeJob PqJob;     // img: [8 ob][8 ks][64][8]; ob < 4 -> P rows, >= 4 -> Q rows
 
 template <int NJOBS>
 __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
@@ -2053,26 +1516,14 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
             if (ok) {
-                if (ob < 4) {
-                    // P leaves as (hi, lo) bf16 words in accumulator-row order: word 32ob + m <-> channel ch_nat(ob, m),
-                    // m = (i & 3) + 4h + 8(i >> 2) for register i - the A operand of the fused kernel's P-injection MFMA
-#if RN_P_F16
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(jbq.p) + (size_t)row * RN_D + 32 * ob + 4 * h;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        *reinterpret_cast<uint2*>(dst + 8 * v) = make_uint2(p_pack2(acc[4 * v], acc[4 * v + 1]), p_pack2(acc[4 * v + 2], acc[4 * v + 3]));
-#else
-                    unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + (size_t)row * RN_D + 32 * ob + 4 * h;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
-                                                                        split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
-#endif
-                } else {
-                    u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + (size_t)row * RN_D + 32 * (ob - 4) + 16 * h);
-                    dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
-                    dst[1] = u32x4{pack2(acc[8], acc[9]), pack2(acc[10], acc[11]), pack2(acc[12], acc[13]), pack2(acc[14], acc[15])};
-                }
+                // both tables leave as f16 in NATURAL channel order: register i of lane half h holds channel 32 ob' + 16 h + i of its block (rows in
+                // ch_nat order), or 32 ob' + 8 h + i / 32 ob' + 16 + 8 h + (i - 8) (P rows of a depth-1 edge MLP: ch_efrag order) - two 16-byte stores
+                bf16_t* row_p = (ob < 4 ? jbq.p : jbq.q) + (size_t)row * RN_D + 32 * (ob & 3);
+                const bool efr = ob < 4 && jbq.p_efrag;
+                u32x4* d0 = reinterpret_cast<u32x4*>(row_p + (efr ? 8 * h : 16 * h));
+                u32x4* d1 = reinterpret_cast<u32x4*>(row_p + (efr ? 16 + 8 * h : 16 * h + 8));
+                *d0 = u32x4{p_pack2(acc[0], acc[1]), p_pack2(acc[2], acc[3]), p_pack2(acc[4], acc[5]), p_pack2(acc[6], acc[7])};
+                *d1 = u32x4{p_pack2(acc[8], acc[9]), p_pack2(acc[10], acc[11]), p_pack2(acc[12], acc[13]), p_pack2(acc[14], acc[15])};
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -2080,176 +1531,6 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     NU_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NU_STAMP(5);
-}
-
-// The same update with ONE workgroup per RNA (n <= 256): GraphNorm statistics (two-pass), normalisation and the projections in one launch -
-// no k_gn_coef launch, no coefficient round trip through HBM.  The rows are read three times (two statistics passes in a
-// (channel quad, row group) mapping, then the MFMA mapping), the second and third time from L2.
-template <int NJOBS>
-__global__ void __launch_bounds__(256, 1) k_node_rna(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
-        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ h_out, PqJob j0, PqJob j1) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* img = reinterpret_cast<u32x4*>(smem);
-    float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);          // [NJOBS][128]
-    float* lds_coef = lds_bias + 256;                                           // a[128] | b[128]
-    float4* red = reinterpret_cast<float4*>(lds_coef + 256);                    // [4 waves][32 quads]
-    const int b = blockIdx.x;
-    const int n = pk.len[b];
-    if (n <= 0) return;
-    const int base = pk.cu[b];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    {   // ---- statistics: thread = (channel quad cq, row group g): rows g, g+8, ...
-        const int cq = tid & 31, g = tid >> 5;
-        const float4* xb = reinterpret_cast<const float4*>(x + (size_t)base * RN_D) + cq;
-        const float4* ab = add ? reinterpret_cast<const float4*>(add + (size_t)base * RN_D) + cq : nullptr;
-        auto block_sum = [&](float4 s) -> float4 {                  // over the 8 row groups, fixed order
-            s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64); s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
-            __syncthreads();
-            if (lane < 32) red[wave * 32 + lane] = s;
-            __syncthreads();
-            float4 t = red[cq];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) { const float4 u = red[w * 32 + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-            return t;
-        };
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r0 = g; r0 < n; r0 += 64) {                        // 8 rows per thread in flight
-            float4 v[8], a[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); v[i] = xb[(size_t)rw * 32]; }
-            if (ab) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); a[i] = ab[(size_t)rw * 32]; }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (r0 + 8 * i < n) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
-        }
-        const float4 S = block_sum(s);
-        const float fn = (float)n;
-        const float4 mu = make_float4(S.x / fn, S.y / fn, S.z / fn, S.w / fn);
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r0 = g; r0 < n; r0 += 64) {
-            float4 v[8], a[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); v[i] = xb[(size_t)rw * 32]; }
-            if (ab) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { const int rw = min(r0 + 8 * i, n - 1); a[i] = ab[(size_t)rw * 32]; }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (r0 + 8 * i < n) {
-                const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
-                q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
-            }
-        }
-        const float4 Q = block_sum(q);
-        if (g == 0) {
-            const float pad = (float)(t_tot - n);
-            const float4 sc = reinterpret_cast<const float4*>(scale)[cq], sh = reinterpret_cast<const float4*>(shift)[cq];
-            const float mean[4] = {mu.x, mu.y, mu.z, mu.w}, sq[4] = {Q.x, Q.y, Q.z, Q.w};
-            const float scl[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // var = [sum_valid (x - mu)^2 + (T - n) mu^2] / n : padded rows enter as (0 - mu)^2 (functional.py:33-38)
-                const float var = (sq[i] + pad * mean[i] * mean[i]) / fn;
-                const float av = scl[i] / sqrtf(var + kSEPS);
-                lds_coef[4 * cq + i] = av;
-                lds_coef[128 + 4 * cq + i] = shf[i] - mean[i] * av;
-            }
-        }
-    }
-    // ---- normalise + project, 128 rows of the RNA at a time (one 32-row block per wave)
-    for (int blk0 = 0; blk0 < n; blk0 += 128) {
-        const int rl = blk0 + 32 * wave + r;
-        const bool ok = rl < n;
-        const size_t row = (size_t)base + (ok ? rl : n - 1);
-        f32x4 vx[8][2], va[8][2];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int c0 = 16 * s + 8 * h;
-            vx[s][0] = *reinterpret_cast<const f32x4*>(x + row * RN_D + c0);
-            vx[s][1] = *reinterpret_cast<const f32x4*>(x + row * RN_D + c0 + 4);
-            if (add) {
-                va[s][0] = *reinterpret_cast<const f32x4*>(add + row * RN_D + c0);
-                va[s][1] = *reinterpret_cast<const f32x4*>(add + row * RN_D + c0 + 4);
-            }
-        }
-        if (blk0 == 0) {        // weight images and biases -> LDS while the row loads fly
-            __builtin_amdgcn_sched_barrier(0);
-            stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
-            if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
-            if (tid < 128) lds_bias[tid] = j0.bias[tid];
-            else if (NJOBS > 1) lds_bias[tid] = j1.bias[tid - 128];
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                                         // images, biases and the coefficients are visible
-        }
-        if (add) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { vx[s][0] += va[s][0]; vx[s][1] += va[s][1]; }
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int c0 = 16 * s + 8 * h;
-            const f32x4 ca0 = *reinterpret_cast<const f32x4*>(lds_coef + c0), ca1 = *reinterpret_cast<const f32x4*>(lds_coef + c0 + 4);
-            const f32x4 cb0 = *reinterpret_cast<const f32x4*>(lds_coef + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(lds_coef + 128 + c0 + 4);
-            vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
-        }
-        u32x4 xf[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 v0 = vx[s][0], v1 = vx[s][1];
-            xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
-        }
-        if (ok && h_out) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int c0 = 16 * s + 8 * h;
-                *reinterpret_cast<f32x4*>(h_out + row * RN_D + c0) = vx[s][0];
-                *reinterpret_cast<f32x4*>(h_out + row * RN_D + c0 + 4) = vx[s][1];
-            }
-        }
-#pragma unroll
-        for (int jb = 0; jb < NJOBS; ++jb) {
-            const PqJob& jbq = jb == 0 ? j0 : j1;
-            const u32x4* im = img + jb * 4096;
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob) {
-                f32x16 acc;
-                if (ob < 4) acc = init_vec16(lds_bias + jb * 128 + 32 * ob + 16 * h);
-                else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
-                if (ok) {
-                    if (ob < 4) {
-#if RN_P_F16
-                        bf16_t* dst = reinterpret_cast<bf16_t*>(jbq.p) + row * RN_D + 32 * ob + 4 * h;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            *reinterpret_cast<uint2*>(dst + 8 * v) = make_uint2(p_pack2(acc[4 * v], acc[4 * v + 1]), p_pack2(acc[4 * v + 2], acc[4 * v + 3]));
-#else
-                        unsigned* dst = reinterpret_cast<unsigned*>(jbq.p) + row * RN_D + 32 * ob + 4 * h;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            *reinterpret_cast<u32x4*>(dst + 8 * v) = u32x4{split_word(acc[4 * v]), split_word(acc[4 * v + 1]),
-                                                                            split_word(acc[4 * v + 2]), split_word(acc[4 * v + 3])};
-#endif
-                    } else {
-                        u32x4* dst = reinterpret_cast<u32x4*>(jbq.q + row * RN_D + 32 * (ob - 4) + 16 * h);
-                        dst[0] = u32x4{pack2(acc[0], acc[1]), pack2(acc[2], acc[3]), pack2(acc[4], acc[5]), pack2(acc[6], acc[7])};
-                        dst[1] = u32x4{pack2(acc[8], acc[9]), pack2(acc[10], acc[11]), pack2(acc[12], acc[13]), pack2(acc[14], acc[15])};
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
 }
 
 // [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256].
@@ -2273,21 +1554,8 @@ void launch_build_pq_image(const float* w0, const float* b1, int efrag, bf16_t* 
 }
 
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
-                        float* coef, float* h_out, int njobs, const bf16_t* img0, const float* bias0, float* p0, bf16_t* q0,
-                        const bf16_t* img1, const float* bias1, float* p1, bf16_t* q1, hipStream_t s) {
-    PqJob j0{img0, bias0, p0, q0}, j1{img1, bias1, p1, q1};
-    // opt-in (RNAMPNN_NODE_RNA=1): measured SLOWER on C2 - 39.6 us per layer against 24.6 + 10.3 us of the two-kernel form: one
-    // workgroup per CU walks three dependent passes over its rows plus the image staging, with nothing else to hide them behind
-    static const bool use_rna = [] { const char* e = getenv("RNAMPNN_NODE_RNA"); return e && e[0] == '1'; }();
-    if (scale && pk.T <= 256 && use_rna) {      // one workgroup per RNA: statistics + normalisation + projections in one launch
-        static DevAttr a1, a2;
-        const size_t l1 = 65536 + 1024 + 1024 + 2048, l2 = 131072 + 1024 + 1024 + 2048;
-        ensure_dyn_lds((const void*)k_node_rna<1>, l1, a1);
-        ensure_dyn_lds((const void*)k_node_rna<2>, l2, a2);
-        if (njobs == 1) hipLaunchKernelGGL(k_node_rna<1>, dim3(pk.B), dim3(256), l1, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1);
-        else hipLaunchKernelGGL(k_node_rna<2>, dim3(pk.B), dim3(256), l2, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1);
-        return;
-    }
+                        float* coef, float* h_out, int njobs, const NodeJob& job0, const NodeJob& job1, hipStream_t s) {
+    const PqJob j0 = job0, j1 = njobs > 1 ? job1 : NodeJob{};
     if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     dim3 grid((pk.Nmax + 127) / 128);
     // Measured and NOT kept (round 3, C2, 21.9 us per launch for this form): (a) four workgroups per 128-row block (one per job and P / Q half,

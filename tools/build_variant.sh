@@ -7,5 +7,5 @@ C=$ROOT/rna-mpnn_amd/csrc
 name=$1; shift
 mkdir -p $C/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value "$@" -I$ROOT/include -I$C \
-    -o $C/variants/$name.so $C/api.cpp $C/kernels_f32.hip $C/kernels_bf16.hip $C/kernels_train.hip $C/rdesign.hip $C/gbdt.hip
+    -o $C/variants/$name.so $C/api.cpp $C/kernels_f32.hip $C/kernels_bf16.hip $C/kernels_mpnn.hip $C/kernels_train.hip $C/rdesign.hip $C/gbdt.hip
 echo built $C/variants/$name.so
