@@ -204,7 +204,7 @@ def main():
     dev_batches = [(torch.from_numpy(c).to(dev), torch.from_numpy(m).to(dev), torch.from_numpy(y).to(dev)) for c, m, y in batches]
 
     def run_forward(batch_list, steps, warmup, profile):
-        """W untimed + K timed passes over the resident batches -> (elapsed seconds of this rank, last logits, kernel ms, launches)."""
+        """W untimed + K timed passes over the resident batches -> (elapsed seconds of this rank, last logits, timed fused launches by kind)."""
         def one():
             o = None
             for c, m, _ in batch_list:
@@ -222,13 +222,13 @@ def main():
             o = one()
         barrier()
         el = time.perf_counter() - t0
-        km, nl = (0.0, 0)
+        km, nl = ((0.0, 0), (0.0, 0))
         if model is not None and profile:
-            km, nl = model.profile_read(reset=True)
+            km, nl = model.profile_read_kinds(reset=True)      # ((ms, n) of the <edge, message> launches, (ms, n) of the message-only launch)
             model.profile_enable(False)
         return el, o, km, nl
 
-    elapsed, logits, kern_ms, launches = run_forward(dev_batches, args.steps, args.warmup, True)
+    elapsed, logits, prof_em, prof_first = run_forward(dev_batches, args.steps, args.warmup, True)
     t_max, nt_total = shard.reduce_job(elapsed, float(nt_rank), red_dev)
     value = nt_total * args.steps / t_max
 
@@ -267,18 +267,23 @@ def main():
     if rank == 0:
         n_mean = float(lens.mean())
         w = 2 if args.precision == "bf16" else 4
-        # algorithmic HBM bytes of ONE launch of the fused ResMPNN edge kernel, per nucleotide:
-        #   e read + e write (k*128*w each; the last layer's launch only reads) + neighbour index (k*4)
-        #   + P|Q rows of both MLPs (2*256*4) + h read + h_pre write (2*128*4)
+        # Roofline of the dominant kernel = the <edge update of layer l, message of layer l + 1> launch of the fused ResMPNN kernel (L - 1 = 9 per
+        # forward), timed live with HIP events on the launch stream, separately from the message-only launch of layer 1.
+        #   achieved = SURVEY section 8(d)'s algorithmic bytes of one ResMPNN layer per nucleotide - e read + write 2 k 128 w, h read / write 4 * 128 w,
+        #   neighbour index 2 * 4 k (16,624 B at k = 30, w = 2) - x the nucleotides of a launch / the launch's duration.
+        #   kernel_bytes_per_nt = what THIS kernel moves per nucleotide at its stored widths: e read + write (f16), index once, its own P rows of both
+        #   MLPs (f16), the gathered Q rows counted once per table row (f16, L2-resident), the residue's h (f32) and the h + mean row it writes (f32).
         L = 10
-        bytes_mid = k * (2 * 128 * w + 4) + 2 * 256 * 4 + 2 * 128 * 4
-        bytes_first = k * (128 * w + 4) + 256 * 4 + 2 * 128 * 4            # layer 1: message only, reads e once
-        bytes_launch_nt = (bytes_first + (L - 1) * bytes_mid) / L           # mean over the L launches of a forward
-        launch_ms = kern_ms / max(launches, 1)
+        survey_bytes_nt = k * (2 * 128 * w + 2 * 4) + 4 * 128 * w
+        kernel_bytes_nt = k * (2 * 128 * w + 4) + 4 * 128 * 2 + 2 * 128 * 4
+        first_bytes_nt = k * (128 * w + 4) + 2 * 128 * 2 + 2 * 128 * 4       # layer 1: message only - e read once, one P and one Q table
+        (ms_em, n_em), (ms_first, n_first) = prof_em, prof_first
+        launch_ms = ms_em / max(n_em, 1)
+        first_ms = ms_first / max(n_first, 1)
         nt_call = nt_rank / len(batches)                                    # nucleotides one launch works on
         measured_cfg = args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch and world == 1
         traffic, traffic_src = None, None   # HBM bytes per launch from PMC counters, when a profile of this workload is committed
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(REPO, "profiles", cand)))
                 if measured_cfg:
@@ -286,15 +291,26 @@ def main():
                 break
             except Exception:
                 continue
-        achieved_gbs = bytes_launch_nt * nt_call / (launch_ms * 1e-3) / 1e9 if launches else 0.0
+        achieved_gbs = survey_bytes_nt * nt_call / (launch_ms * 1e-3) / 1e9 if n_em else 0.0
         exec_flops_nt = flops_per_nt(k, n_mean, factored=True)
         model_flops_nt = flops_per_nt(k, n_mean)
         per_rank_rate = nt_rank * args.steps / elapsed
-        roof = {"bound": "hbm", "kernel": "fused ResMPNN edge kernel (k_mpnn_*)",
+        # matrix-pipe share of the same launch: one 32-slot block per residue (k > 16), 128 v_mfma_f32_32x32x16 per block (160 in the round-3
+        # kernel, RNAMPNN_MPNN_V3=1: 32 helper MFMAs), 32,768 FLOP each; useful = the k real edge slots of the 32
+        mfma_per_block = 160 if os.environ.get("RNAMPNN_MPNN_V3") == "1" else 128
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        issued_tf = nt_call * mfma_per_block * 32768 / (launch_ms * 1e-3) / 1e12 if (n_em and args.precision == "bf16" and k > 16) else None
+        roof = {"bound": "hbm", "kernel": "fused ResMPNN kernel, <edge update, message> launch (k_resmpnn<true, true>)",
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "launch_ms": launch_ms, "launches_timed": launches,
-                "algorithmic_bytes_per_nt_per_launch": bytes_launch_nt, "nucleotides_per_launch": nt_call}
+                "launch_ms": launch_ms, "launches_timed": n_em,
+                "algorithmic_bytes_per_nt_per_launch": survey_bytes_nt, "kernel_bytes_per_nt": kernel_bytes_nt,
+                "nucleotides_per_launch": nt_call,
+                "mfma_issued_frac": issued_tf / peak_tf if issued_tf else None,
+                "mfma_useful_frac": issued_tf * min(k, 32) / 32 * 128 / mfma_per_block / peak_tf if issued_tf else None,
+                "first_launch": {"kernel": "message-only launch of layer 1 (k_resmpnn<false, true>)", "launch_ms": first_ms, "launches_timed": n_first,
+                                 "algorithmic_bytes_per_nt": first_bytes_nt,
+                                 "achieved": first_bytes_nt * nt_call / (first_ms * 1e-3) / 1e9 if n_first else None}}
         if measured_cfg and traffic_src:    # measured on exactly this configuration (profiles/)
             roof["traffic_note"] = f"bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/{traffic_src}"
         out = {

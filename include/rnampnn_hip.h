@@ -235,6 +235,9 @@ int     rnampnn_adam_step(float* param, const float* grad, float* exp_avg, float
  * No reference counterpart (the reference has no profiling hooks). */
 int rnampnn_profile_enable(rnampnn_handle h, int32_t enable);
 int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset);
+/* The same split by launch kind: index 0 = launches that run the edge update of layer l AND the message of layer l + 1 (L - 1 per forward),
+ * index 1 = the other fused launches (the message-only launch of layer 1, an edge-only launch of a tap). */
+int rnampnn_profile_read_kinds(rnampnn_handle h, double* kernel_ms2, int64_t* launches2, int32_t reset);
 
 const char* rnampnn_last_error(void);
 const char* rnampnn_version(void);

@@ -94,8 +94,9 @@ struct rnampnn_ctx {
     long long prof_seen = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
-    double prof_ms = 0.0;
-    long long prof_n = 0;
+    std::vector<unsigned char> ev_kind;   // per event pair: 0 = <edge update, message> launch, 1 = message-only / edge-only launch
+    double prof_ms = 0.0, prof_ms_kind[2] = {0.0, 0.0};
+    long long prof_n = 0, prof_n_kind[2] = {0, 0};
     // tapes of rnampnn_train_forward calls whose backward may still come (the activations themselves live in the caller's
     // workspaces): one record per workspace, identified by a monotonically increasing id that rnampnn_train_backward must present
     struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; const unsigned long long* seed_dev; };
@@ -287,6 +288,7 @@ extern "C" int rnampnn_profile_enable(rnampnn_handle h, int32_t enable) {
     if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
     if (enable && h->ev.empty()) {
         h->ev.resize(2 * 8192);
+        h->ev_kind.assign(8192, 0);
         for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
     }
     h->prof = enable != 0;
@@ -295,19 +297,39 @@ extern "C" int rnampnn_profile_enable(rnampnn_handle h, int32_t enable) {
     return RNAMPNN_OK;
 }
 
-extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset) {
-    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+static int profile_collect(rnampnn_handle h) {
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-        h->prof_ms += ms;
-        h->prof_n += 1;
+        const int kind = h->ev_kind[i / 2] ? 1 : 0;
+        h->prof_ms += ms; h->prof_n += 1;
+        h->prof_ms_kind[kind] += ms; h->prof_n_kind[kind] += 1;
     }
     h->ev_used = 0;
+    return RNAMPNN_OK;
+}
+static void profile_reset(rnampnn_handle h) {
+    h->prof_ms = 0.0; h->prof_n = 0;
+    for (int i = 0; i < 2; ++i) { h->prof_ms_kind[i] = 0.0; h->prof_n_kind[i] = 0; }
+}
+
+extern "C" int rnampnn_profile_read(rnampnn_handle h, double* kernel_ms, int64_t* launches, int32_t reset) {
+    if (!h) return fail(RNAMPNN_ERR_BAD_ARG, "null handle");
+    int rc = profile_collect(h);
+    if (rc) return rc;
     if (kernel_ms) *kernel_ms = h->prof_ms;
     if (launches) *launches = h->prof_n;
-    if (reset) { h->prof_ms = 0.0; h->prof_n = 0; }
+    if (reset) profile_reset(h);
+    return RNAMPNN_OK;
+}
+
+extern "C" int rnampnn_profile_read_kinds(rnampnn_handle h, double* kernel_ms2, int64_t* launches2, int32_t reset) {
+    if (!h || !kernel_ms2 || !launches2) return fail(RNAMPNN_ERR_BAD_ARG, "rnampnn_profile_read_kinds: null argument");
+    int rc = profile_collect(h);
+    if (rc) return rc;
+    for (int i = 0; i < 2; ++i) { kernel_ms2[i] = h->prof_ms_kind[i]; launches2[i] = h->prof_n_kind[i]; }
+    if (reset) profile_reset(h);
     return RNAMPNN_OK;
 }
 
@@ -616,7 +638,7 @@ static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in,
     rnampnn_ctx* c = r.c;
     int k = c->cfg.num_res_neighbours;
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
-    if (timed) (void)hipEventRecord(c->ev[c->ev_used], r.s);
+    if (timed) { c->ev_kind[c->ev_used / 2] = (we && wm) ? 0 : 1; (void)hipEventRecord(c->ev[c->ev_used], r.s); }
     if (r.fast) {
         launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.p_e, r.w.q_e, r.w.p_m,
                          r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1,
@@ -722,7 +744,12 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
     // ---- ResFeature.forward (feature.py:588-592)
     launch_geom(io->coords, r.pk, io->raw, w.raw_p, w.geom, r.fast ? w.geomh : nullptr, s);
     const bool fused_first = r.fast && io->stop_after != 1;
-    gemm(r, c->raw_project, w.raw_p, RN_RAWP, w.n0, RN_D);
+    {   // raw_project (feature.py:183, 28 -> 128) in exact f32 on both paths: the GraphNorm behind the embedding stack removes the common part of
+        // its output and amplifies the rounding of the inputs (bf16 operands here cost 4 % of h0: tools/tap_errors.py); 0.1 GFLOP at the C2 batch
+        const Lin& l = c->raw_project;
+        launch_gemm_f32(r.ntot(), r.pk.Nmax, w.raw_p, RN_RAWP, l.in_pad, nullptr, 0, 0, derp<float>(c, l.wt), rawp(c, l.b), l.out,
+                        l.gelu ? 1 : 0, nullptr, 0, w.n0, RN_D, r.s);
+    }
     rc = run_bert(r, c->emb, w.n0, w.n1);
     if (!rc) {
         if (fused_first)    // GraphNorm + the [P | Q] projection of layer 1's message MLP in one pass

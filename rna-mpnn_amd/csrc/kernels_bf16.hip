@@ -112,7 +112,7 @@ __global__ void k_build_embed_image(const float* __restrict__ w0, const float* _
         int j = id & 7, lane = (id >> 3) & 63, f = id >> 9;
         int mb = f / EMB_KS, s = f % EMB_KS, r = lane & 31, h = lane >> 5;
         int feat = emb_feature_of_slot(h, 8 * s + j);
-        img[id] = feat >= 0 ? f2bf(kGA * w0[(size_t)ch_nat(mb, r) * RN_ERAW + feat]) : (bf16_t)0;     // (scaled domain: y1 = a (W0 f + b0))
+        img[id] = feat >= 0 ? __builtin_bit_cast(bf16_t, (_Float16)(kGA * w0[(size_t)ch_nat(mb, r) * RN_ERAW + feat])) : (bf16_t)0;     // f16 (scaled domain: y1 = a (W0 f + b0))
     } else if (id < n0 + n1) {
         int e = id - n0;
         int j = e & 7, lane = (e >> 3) & 63, f = e >> 9;
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
 #pragma unroll
         for (int s = 0; s < EMB_KS; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xf[s][t] = pack2(ft[8 * s + 2 * t], ft[8 * s + 2 * t + 1]);
+            for (int t = 0; t < 4; ++t) xf[s][t] = p_pack2(ft[8 * s + 2 * t], ft[8 * s + 2 * t + 1]);      // f16: distances keep 11 significand bits (8 as bf16)
         RN_EE_FENCE();
         // ---- requests of the next two blocks (their latency passes under this block's matrix work)
         const unsigned vmask = j_cur >= 0 ? 0xffffffffu : 0u;
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
         for (int mb = 0; mb < 4; ++mb) {
             f32x16 acc = init_vec16(lds_b + 32 * mb + 16 * h);
 #pragma unroll
-            for (int s = 0; s < EMB_KS; ++s) acc = mfma32(img[(mb * EMB_KS + s) * 64 + lane], xf[s], acc);
+            for (int s = 0; s < EMB_KS; ++s) acc = mfma32h(img[(mb * EMB_KS + s) * 64 + lane], xf[s], acc);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {           // packed-f16 GELU, hidden activations stay f16 (as in the fused kernel)
                 const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
@@ -1085,6 +1085,9 @@ struct ChainW {
 // chunk, so "chunk c has landed" is the counted wait vmcnt(8 * chunks issued after c) followed by a
 // raw s_barrier (a __syncthreads() would drain the ring: cdna guide, "Pipelining across barriers").
 #define CH_RING 4
+#ifndef CH_GELU
+#define CH_GELU 1
+#endif
 __device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4* ring, int c, int tid) {
     const u32x4* src = img + (size_t)c * 2048 + tid;
     u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63);          // wave-uniform base; the DMA adds lane * 16
@@ -1139,8 +1142,16 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
 #ifdef CH_EXP_NOGELU
             const f16x4 g = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
 #else
+#if CH_GELU == 2           /* experiment: f32 sigmoid-form GELU (2.7e-4) */
+            const f16x4 g = cvt_h4(gelu_fast(acc[2 * t]), gelu_fast(acc[2 * t + 1]), gelu_fast(acc[8 + 2 * t]), gelu_fast(acc[8 + 2 * t + 1]));
+#else
             const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
+#if CH_GELU == 1
+            const f16x4 g = x * phi4_hi(x);        // packed-f16 GELU, five-coefficient Phi (1.2e-3): what follows a node chain is a GraphNormalization
+#else
             const f16x4 g = x * phi4(x);           // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
+#endif
+#endif
 #endif
             out[2 * ob][t] = __builtin_bit_cast(unsigned, lo2(g));
             out[2 * ob + 1][t] = __builtin_bit_cast(unsigned, hi2(g));
@@ -1167,7 +1178,7 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
 #ifdef CH_EXP_NOMFMA      /* ablation: no matrix work (wrong results) */
                 acc[0] += __uint_as_float(fr[m & 7][0] ^ in[ks][0]);
 #else
-                acc = C0 == 0 ? mfma32(fr[m & 7], in[ks], acc) : mfma32h(fr[m & 7], in[ks], acc);    // hidden activations are f16
+                acc = mfma32h(fr[m & 7], in[ks], acc);    // f16 operands in every layer
 #endif
                 if constexpr (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
                 if constexpr (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
@@ -1239,7 +1250,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
         }
 #pragma unroll
         for (int s = 0; s < K0 / 16; ++s)
-            a[s] = u32x4{pack2(v0[s][0], v0[s][1]), pack2(v0[s][2], v0[s][3]), pack2(v1[s][0], v1[s][1]), pack2(v1[s][2], v1[s][3])};
+            a[s] = u32x4{p_pack2(v0[s][0], v0[s][1]), p_pack2(v0[s][2], v0[s][3]), p_pack2(v1[s][0], v1[s][1]), p_pack2(v1[s][2], v1[s][3])};      // f16
     }
     __syncthreads();                                          // biases visible; no DMA is in flight yet
     const u32x4* img = reinterpret_cast<const u32x4*>(w.img);
@@ -1272,7 +1283,8 @@ __global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, 
     int row = ch_nat(ob, r);
     int col = first ? 16 * ks + 8 * h + j : 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j;
     const float wv = (row < n_real && col < K_real) ? wraw[(size_t)row * K_real + col] : 0.f;
-    dst[id] = first ? f2bf(wv) : __builtin_bit_cast(bf16_t, (_Float16)wv);      // layers after the first consume f16 activations
+    dst[id] = __builtin_bit_cast(bf16_t, (_Float16)wv);      // every layer consumes f16 operands (the first one too since round 4: the input rows keep 11
+                                                             // significand bits instead of 8 - see tools/tap_errors.py: the GraphNorm behind the node stacks amplifies input rounding)
 }
 void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s) {
     int total = (N / 32) * (K / 16) * 512;
@@ -1483,7 +1495,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const f32x4 v0 = vx[s][0], v1 = vx[s][1];
-        xf[s] = u32x4{pack2(v0[0], v0[1]), pack2(v0[2], v0[3]), pack2(v1[0], v1[1]), pack2(v1[2], v1[3])};
+        xf[s] = u32x4{p_pack2(v0[0], v0[1]), p_pack2(v0[2], v0[3]), p_pack2(v1[0], v1[1]), p_pack2(v1[2], v1[3])};      // f16 rows, f16 images
     }
 #ifdef RN_DMA_STAGE
     __builtin_amdgcn_sched_barrier(0);
@@ -1514,7 +1526,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mfma32(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
+            for (int ks = 0; ks < 8; ++ks) acc = mfma32h(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
             if (ok) {
                 // both tables leave as f16 in NATURAL channel order: register i of lane half h holds channel 32 ob' + 16 h + i of its block (rows in
                 // ch_nat order), or 32 ob' + 8 h + i / 32 ob' + 16 + 8 h + (i - 8) (P rows of a depth-1 edge MLP: ch_efrag order) - two 16-byte stores
@@ -1543,7 +1555,7 @@ __global__ void k_build_pq_image(const float* __restrict__ w0, const float* __re
     if (id >= 8 * 8 * 64 * 8) return;
     int j = id & 7, lane = (id >> 3) & 63, f = id >> 9, ob = f >> 3, ks = f & 7, r = lane & 31, h = lane >> 5;
     int row = (efrag && ob < 4) ? ch_efrag(ob, r) : ch_nat(ob & 3, r), col = (ob < 4 ? 0 : 128) + 16 * ks + 8 * h + j;
-    dst[id] = f2bf(kGA * w0[(size_t)row * 384 + col]);          // (scaled domain: the tables hold a P and a Q)
+    dst[id] = __builtin_bit_cast(bf16_t, (_Float16)(kGA * w0[(size_t)row * 384 + col]));          // f16 (scaled domain: the tables hold a P and a Q)
     if (id < 128) {
         int ob2 = id >> 5, m = id & 31, hh = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
         b1p[32 * ob2 + 16 * hh + i] = kGA * b1[efrag ? ch_efrag(ob2, m) : ch_nat(ob2, m)];

@@ -79,6 +79,7 @@ SYMBOLS = {
     "rnampnn_loss_and_grad": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _F, C.c_uint64, _I32, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_profile_enable": (C.c_int, [_VP, _I32]),
     "rnampnn_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
+    "rnampnn_profile_read_kinds": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), _I32]),
     "rnampnn_edge_raw_workspace_bytes": (_SZ, [_VP, _I32, _I32]),
     "rnampnn_edge_raw_features": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _SZ, _VP]),
     "rnampnn_gbdt_create": (C.c_int, [_I32, _I32, _I32, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),

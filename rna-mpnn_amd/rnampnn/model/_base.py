@@ -181,3 +181,9 @@ class NativeModule(nn.Module):
         ms, n = C.c_double(), C.c_int64()
         _native.check(_native.lib().rnampnn_profile_read(self._handle.ptr, C.byref(ms), C.byref(n), 1 if reset else 0))
         return float(ms.value), int(n.value)
+
+    def profile_read_kinds(self, reset: bool = True):
+        """-> ((ms, launches) of the <edge update, message> launches, (ms, launches) of the other fused launches) since the last reset."""
+        ms, n = (C.c_double * 2)(), (C.c_int64 * 2)()
+        _native.check(_native.lib().rnampnn_profile_read_kinds(self._handle.ptr, ms, n, 1 if reset else 0))
+        return (float(ms[0]), int(n[0])), (float(ms[1]), int(n[1]))

@@ -282,16 +282,25 @@ def test_bf16_path_within_tolerance(golden, name):
         print(f"per-channel mean |de1| over {int(okb.sum())} edges: min {per_ch.min():.3e} median {np.median(per_ch):.3e} max {per_ch.max():.3e}; "
               f"|de0|: min {per_ch0.min():.3e} median {np.median(per_ch0):.3e} max {per_ch0.max():.3e}; worst channels {worst.tolist()} "
               f"err {per_ch[worst].round(4).tolist()} mean|e1| {sig[worst].round(3).tolist()} (median mean|e1| {np.median(sig):.3f})")
-        assert per_ch.max() < 0.25 * max(sig.max(), 1e-3), (per_ch.max(), sig.max())       # a mis-routed channel would be off by its own magnitude
+        assert per_ch.max() < 0.25 * max(sig.max(), 1e-3), (per_ch.max(), sig.max())
+        # ... and every channel against its OWN mean signal: a mis-routed channel (wrong routing fragment / row order) is off by ~100 % of it.
+        # Measured worst ratio 0.34 (channel 116: 0.060 on 0.177; median 0.02): the one-Linear update adds GELU(P + Q + e Wc) to e with nothing
+        # behind it that averages the f16 rounding of the three large terms of its pre-activation
+        ratio = per_ch / np.maximum(sig, 1e-3)
+        print(f"per-channel |de1| / mean|e1|: median {np.median(ratio):.3f} max {ratio.max():.3f} (channel {int(ratio.argmax())})")
+        assert ratio.max() < 0.5, (int(ratio.argmax()), float(ratio.max()))
         assert dh < 5e-2
     logits = model(coords, mask).cpu().numpy()
     assert np.isfinite(logits).all()
     err = np.abs(logits - arrs["logits"]).max()
     assert err < bf16_tol(arrs["logits"], arrs["mask"]), f"{name}: |dlogit| = {err:.3e}"
+    # Measured since round 4 (f16 operands in every node-level first Linear, raw_project in f32, five-coefficient Phi in the node FFN chains - the
+    # GraphNormalization behind a node stack amplifies what enters it, tools/tap_errors.py): 2.4e-3 .. 3.6e-3 at k = 30, 4.3e-3 on the T = n
+    # goldens of BASELINE config 1 (k = 16, k = 3; 1.8e-2 in round 3), 8.1e-3 on the one-Linear edge update of alt_cfg_k4.  A third of the generic
+    # floor is asserted everywhere, a fifth at k = 30 (SURVEY 8c's bound for this path is 5e-2).
+    assert err < BF16_LOGIT_TOL / 3, f"{name}: |dlogit| = {err:.3e}"
     if int(hp.get("num_res_neighbours", 30)) > 16:
-        # the one-residue-per-block kernel of the BASELINE configurations (k = 30): measured 7.0e-3 .. 7.3e-3 on these goldens since e and the P tables
-        # are stored as f16 (2.2e-2 in round 2); half the generic floor is asserted.  (k <= 16 packs several residues per block: 1.8e-2 measured.)
-        assert err < 0.5 * BF16_LOGIT_TOL, f"{name}: |dlogit| = {err:.3e}"
+        assert err < BF16_LOGIT_TOL / 5, f"{name}: |dlogit| = {err:.3e}"
     assert (logits[arrs["mask"] == 0] == 0).all()
     labels = arrs["labels"]
     valid = arrs["mask"] > 0

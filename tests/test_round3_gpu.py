@@ -160,7 +160,9 @@ def test_chunked_allreduce_events_and_trainer_loop():
 def test_matched_recovery_on_trained_logits_64_rnas():
     """SURVEY 8c second half at a size that means something: 64 RNAs of the C2 length mix, bf16-mixed training
     WITH dropout 0.4 until the logits are separated, then f32 CPU oracle vs bf16 HIP forward on the same weights for the
-    first 16 RNAs: argmax agreement >= 99 %, |delta recovery| <= 0.5 pt."""
+    first 16 RNAs: argmax agreement >= 99.5 %, |delta recovery| <= 0.5 pt, max |delta logit| <= 5 % of the logit spread (measured in round 4:
+    0.085 on a spread of 4.06 = 2.1 %, agreement 0.9974; 0.274 = 6.7 % and 0.9922 in round 3, before the node-level first Linears took f16
+    operands and the node FFN chains the five-coefficient Phi)."""
     import sys, os
     from conftest import REPO
     sys.path.insert(0, REPO)
@@ -177,8 +179,9 @@ def test_matched_recovery_on_trained_logits_64_rnas():
     out = bench.trained_recovery(args, hp, sd, coords, mask, labels, np.asarray(lens), torch.device("cuda:0"), 300)
     print(out)
     assert out["loss_last"] < out["loss_first"]
-    assert out["argmax_agreement"] >= 0.99, out
+    assert out["argmax_agreement"] >= 0.995, out
     assert abs(out["recovery_bf16_hip"] - out["recovery_f32_oracle"]) <= 0.005, out
+    assert out["max_abs_dlogit"] <= 0.05 * out["logit_std"], out
 
 
 def test_captured_train_step_equals_eager_and_draws_fresh_masks():
