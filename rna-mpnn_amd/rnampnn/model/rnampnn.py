@@ -163,6 +163,7 @@ class RNAMPNN(NativeModule):
             ws, ws_bytes = self._ws_ptr(lease.slot)
             _native.check(_native.lib().rnampnn_train_backward(self._handle.ptr, C.c_int64(lease.tape_id), _ptr(d), B, T,
                                                                0 if fresh else 1, _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
+        self._mark_grad_events(True)
 
     def _forward_train(self, coords, mask, T_norm: int = 0, dropout: Optional[float] = None, seed: Optional[int] = None):
         """The reference's ``self(coords, mask)`` inside ``training_step`` (rnampnn.py:199): logits carrying an autograd
@@ -298,6 +299,7 @@ class RNAMPNN(NativeModule):
             _native.check(lib.rnampnn_loss_and_grad(self._handle.ptr, _ptr(c), _ptr(m), _ptr(lab), B, T, int(T_norm), p,
                                                     C.c_uint64(sd & (2 ** 64 - 1)), self._train_flags(), _ptr(loss), _ptr(logits),
                                                     _ptr(self.flat_grad), ws, ws_bytes, _stream(device)))
+        self._mark_grad_events(True)
         return (loss, logits) if return_logits else loss
 
     def _bind_flat_grad(self, device) -> bool:
@@ -358,17 +360,28 @@ class RNAMPNN(NativeModule):
             for ev in evs:
                 ev.record(torch.cuda.current_stream(device))     # (creates the underlying hipEvent_t)
         _native.check(_native.lib().rnampnn_set_grad_events(self._handle.ptr, C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)))
-        self._ar = dict(stream=torch.cuda.Stream(device), events=evs, chunks=self.grad_chunks())
+        self._ar = dict(stream=torch.cuda.Stream(device), events=evs, chunks=self.grad_chunks(), fresh=False)
 
-    def allreduce_gradients(self, timing=None) -> None:
+    def _mark_grad_events(self, fresh: bool) -> None:
+        """The two chunk events are meaningful only for the backward that RECORDED them: an eager ``rnampnn_loss_and_grad`` /
+        ``rnampnn_train_backward`` does (fresh = True); a hipGraph replay of a captured step does not (the capture runs with the events
+        unregistered), and after one use they are spent.  ``allreduce_gradients`` orders a chunk by its event only while fresh and by
+        the whole producing stream otherwise - waiting on a stale, already-completed event would let the side stream read a chunk that
+        the replayed backward is still writing."""
+        ar = getattr(self, "_ar", None)
+        if ar is not None:
+            ar["fresh"] = bool(fresh)
+
+    def allreduce_gradients(self, timing=None, force: bool = False) -> None:
         """Average ``flat_grad`` over the ranks of the default process group (RCCL on the GPUs): the one exchange of
         data-parallel training (Lightning DDP in the reference, utils/train.py:106-117).  After
         ``enable_allreduce_overlap()`` the buffer goes out in the three chunks of ``grad_chunks`` on a side stream, each as
         soon as the backward has finished it; the caller's stream then waits for the side stream.  ``timing``: an optional
         pair of ``torch.cuda.Event(enable_timing=True)`` recorded on the caller's stream around that wait - their distance is
-        the all-reduce time NOT hidden under the backward."""
+        the all-reduce time NOT hidden under the backward.  ``force``: run the exchange at world size 1 too (a sum over one rank;
+        tests drive the RCCL / side-stream path on a one-GPU box with it)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)):
             return
         world = dist.get_world_size()
         ar = getattr(self, "_ar", None)
@@ -379,12 +392,14 @@ class RNAMPNN(NativeModule):
         device = self.flat_grad.device
         main, side = torch.cuda.current_stream(device), ar["stream"]
         inv = 1.0 / world
+        fresh = bool(ar.get("fresh"))
+        ar["fresh"] = False                                  # the events are spent: the next backward has to record them again
         with torch.cuda.stream(side):
             for i, (b, e) in enumerate(ar["chunks"]):
-                if i < 2:
+                if i < 2 and fresh:
                     side.wait_event(ar["events"][i])
                 else:
-                    side.wait_stream(main)                   # the last chunk is final when the backward ends
+                    side.wait_stream(main)                   # the last chunk (and every chunk of a replayed / unknown producer) is final when the stream is
                 if e > b:
                     part = self.flat_grad[b:e]
                     dist.all_reduce(part, op=dist.ReduceOp.SUM)
@@ -716,4 +731,5 @@ class CapturedTrainStep:
         self.mask.copy_(mask, non_blocking=True)
         self.seed.fill_(int(seed) & (2 ** 63 - 1))
         self.graph.replay()
+        m._mark_grad_events(False)                           # (the replay records no chunk events: the exchange must order on the stream)
         return self.loss

@@ -24,24 +24,38 @@ def plan_epoch(lengths: Sequence[int], rank: int, world: int, batch_size: int, m
     """-> (batches of GLOBAL item indices for this rank, per-step padded lengths of this rank).  The batch plan is a pure function
     of (lengths, world, seed): every rank computes the whole plan and takes its column - no communication.  Length-bucketed
     batches are dealt to the ranks round-robin in length order, so step s of every rank holds RNAs of similar length (balanced
-    work per step); all ranks take the same number of steps (the tail that does not fill a round is dropped, as
-    ``DistributedSampler(drop_last=True)`` does)."""
+    work per step) and all ranks take the same number of steps.
+
+    What the reference's loaders do and this plan keeps (``DataLoader(shuffle=True)`` + Lightning's ``DistributedSampler``, which
+    uses ``drop_last=False``): EVERY sample is seen in every epoch, and the composition of the batches changes from epoch to
+    epoch.  (i) The length order that the buckets are cut from is jittered by the seed - an RNA's sort key is its length times a
+    seeded factor in [0.95, 1.05] - so neighbours in length trade places between batches; (ii) a last round that the batches do
+    not fill is padded by REPEATING batches of that round (the sampler pads by wrapping around), never dropped: with a fixed
+    length-sorted order the dropped tail would be the same longest RNAs in every epoch."""
     from . import synth
     import numpy as np
-    order = sorted(range(len(lengths)), key=lambda i: (int(lengths[i]), i))
+    n_items = len(lengths)
+    jit = synth.uniform01(synth._fnv1a64(f"epoch_jitter/{seed}"), np.arange(n_items, dtype=np.uint64))
+    order = sorted(range(n_items), key=lambda i: (int(lengths[i]) * (0.95 + 0.1 * float(jit[i])), i))
     batches: List[List[int]] = []
     cur: List[int] = []
+    cur_max = 0
     for i in order:
         n = int(lengths[i])
-        if cur and (len(cur) >= batch_size or (len(cur) + 1) * n > max_rows):
+        if cur and (len(cur) >= batch_size or (len(cur) + 1) * max(cur_max, n) > max_rows):
             batches.append(cur)
-            cur = []
+            cur, cur_max = [], 0
         cur.append(i)
+        cur_max = max(cur_max, n)
     if cur:
         batches.append(cur)
+    if not batches:
+        raise ValueError("no items")
+    rem = len(batches) % world
+    if rem:                 # pad the unfilled last round by wrapping around its own batches (similar lengths: balanced steps)
+        tail = batches[-rem:]
+        batches = batches + [list(tail[q % rem]) for q in range(world - rem)]
     rounds = len(batches) // world
-    if rounds == 0:
-        raise ValueError(f"{len(batches)} batches cannot feed {world} ranks: lower batch_size / max_rows")
     u = synth.uniform01(synth._fnv1a64(f"epoch_order/{seed}"), np.arange(rounds, dtype=np.uint64))
     perm = np.argsort(u, kind="stable")
     mine = [batches[int(r) * world + rank] for r in perm]

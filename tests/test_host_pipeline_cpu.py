@@ -128,7 +128,16 @@ def test_epoch_plan_pad_batch_and_config3_length_fixture():
     steps = {len(c[0]) for c in cols}
     assert len(steps) == 1
     seen = [i for c in cols for b in c[0] for i in b]
-    assert len(seen) == len(set(seen)) and len(seen) >= 0.95 * len(lens)          # at most the unfilled last round is dropped
+    assert set(seen) == set(range(len(lens)))                    # nothing is dropped: an unfilled last round is padded by repetition ...
+    assert len(seen) - len(set(seen)) <= 3 * 512                  # ... of at most world - 1 of its own batches
+    for world in (4, 8):                                          # every index in every epoch, at every world size; batch composition changes per epoch
+        per_epoch = []
+        for ep in range(3):
+            plan = [plan_epoch(lens, r, world, 512, 32768, seed=10 + ep) for r in range(world)]
+            assert len({len(p[0]) for p in plan}) == 1
+            assert {i for p in plan for b in p[0] for i in b} == set(range(len(lens)))
+            per_epoch.append({tuple(sorted(b)) for p in plan for b in p[0]})
+        assert len(per_epoch[0] & per_epoch[1]) < 0.5 * len(per_epoch[0])
     assert all(cols[0][1] == c[1] for c in cols)                                  # every rank derives the same global lengths
     for s in range(steps.pop()):
         rows = [len(c[0][s]) * max(int(lens[i]) for i in c[0][s]) for c in cols]

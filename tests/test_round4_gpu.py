@@ -1,0 +1,120 @@
+"""Round-4 GPU tests: RCCL at world size 1 through the chunked side-stream gradient exchange (eager and hipGraph-captured producers),
+and the loader -> trainer path after the epoch-plan change."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(precision="bf16", **kw):
+    from rnampnn.model.rnampnn import RNAMPNN
+    from rnampnn.utils import synth
+    hp = dict(num_res_neighbours=30, num_res_mpnn_layers=3, padding_len=64)
+    hp.update(kw)
+    torch.manual_seed(5)
+    model = RNAMPNN(precision=precision, **hp)
+    sd = synth.closed_form_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return model.to("cuda:0").train()
+
+
+@pytest.fixture
+def nccl_world1():
+    """The `nccl` backend of torch.distributed IS RCCL on ROCm: one rank on the one GPU of the box."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_chunked_side_stream_allreduce_equals_the_gradient(nccl_world1):
+    """before the driver's 8-GPU run, RCCL itself executes once - `librccl` loads, `ProcessGroupNCCL` orders its
+    internal stream against the library-recorded chunk events and the join before Adam, and the result of the chunked side-stream
+    exchange is, at world size 1, the un-exchanged gradient bit for bit (sum over one rank, x 1.0).  Three producers: the eager
+    backward (events fresh), a second exchange without a new backward (events spent: stream ordering), and a hipGraph replay of a
+    captured step (no events recorded: stream ordering; ADVICE r3: a stale event must not release a chunk early).  Also prints the
+    exposed all-reduce time of the eager step - the first on real RCCL (one rank: launch + kernel latency only, no xGMI traffic)."""
+    from rnampnn.model.rnampnn import CapturedTrainStep
+    from rnampnn.utils import synth
+    dist = nccl_world1
+    model = _small("bf16")
+    c, m, y = (torch.from_numpy(x).cuda() for x in synth.synth_batch([24, 17, 30, 12], first_index=70))
+    # reference gradient: no exchange at all
+    model.loss_and_grad(y, c, m, seed=11)
+    g_ref = model.flat_grad.clone()
+    # flat (un-chunked) exchange on the caller's stream
+    model.loss_and_grad(y, c, m, seed=11)
+    model.allreduce_gradients(force=True)
+    assert torch.equal(model.flat_grad, g_ref)
+    # chunked exchange on the side stream, ordered by the events the backward records
+    model.enable_allreduce_overlap(True)
+    t = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    for _ in range(3):          # (first call: RCCL communicator set-up on the side stream)
+        model.loss_and_grad(y, c, m, seed=11)
+        assert model._ar["fresh"]
+        model.allreduce_gradients(timing=t, force=True)
+        assert not model._ar["fresh"]
+        torch.cuda.synchronize()
+        assert torch.equal(model.flat_grad, g_ref)
+    print(f"allreduce_exposed_ms at world size 1 over RCCL: {t[0].elapsed_time(t[1]):.3f}")
+    # events spent: a second exchange of the same buffer orders on the stream and still gives the same numbers
+    model.allreduce_gradients(force=True)
+    torch.cuda.synchronize()
+    assert torch.equal(model.flat_grad, g_ref)
+    # hipGraph-captured producer: the replay records no chunk events
+    cap = CapturedTrainStep(model, 4, 30)
+    for _ in range(3):
+        cap(y, c, m, seed=11)
+        assert not model._ar["fresh"]
+        g_replay = None
+        model.allreduce_gradients(force=True)
+        torch.cuda.synchronize()
+        g_replay = model.flat_grad.clone()
+        assert torch.equal(g_replay, g_ref)
+    # a barrier and a scalar all-reduce (the trainer's loss / recovery counters) over the same group
+    s = torch.ones(3, device="cuda:0")
+    dist.all_reduce(s)
+    dist.barrier()
+    assert s.tolist() == [1.0, 1.0, 1.0]
+
+
+def test_trainer_epoch_sees_every_item_with_the_jittered_plan():
+    """the epoch plan drops nothing and changes its batch composition from epoch to epoch; the trainer built on it still
+    runs an epoch end to end (loader -> loss_and_grad -> fused Adam) and counts every nucleotide exactly once at world size 1."""
+    from rnampnn.utils import synth
+    from rnampnn.utils.train import Trainer, plan_epoch
+    model = _small("bf16")
+    lens = [int(n) for n in synth.synth_lengths(40, 10, 48, seed=4)]
+    items = [(synth.synth_rna(n, 900 + i, seed=2), synth.synth_labels(n, 900 + i, seed=2)) for i, n in enumerate(lens)]
+    p0, _ = plan_epoch(lens, 0, 1, 8, 512, seed=0)
+    p1, _ = plan_epoch(lens, 0, 1, 8, 512, seed=1)
+    assert sorted(sum(p0, [])) == list(range(40)) == sorted(sum(p1, []))
+    assert {tuple(sorted(b)) for b in p0} != {tuple(sorted(b)) for b in p1}
+    (opt,), (sched,) = model.configure_optimizers(fused=True)
+    tr = Trainer(model, opt, sched, world=1, rank=0, seed=0)
+    out = tr.run_epoch(items, lens, 0, 8, 512)
+    assert out["nt"] == sum(lens) and np.isfinite(out["train_loss"])
+
+
+def test_two_ranks_on_one_gpu_overlap_equals_flat_allreduce():
+    """the overlapped (chunked, side-stream) gradient exchange with MORE THAN ONE rank, on GPU tensors, against the flat
+    all-reduce - eager backward (chunk events) and hipGraph replay (no events).  Two ranks share the one GPU of the box, so the
+    transport is gloo; RCCL itself runs in the world-size-1 test above.  RCCL overlap across GPUs stays unverified on hardware until
+    a SCALE record with N > 1 exists."""
+    import subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(REPO, "tests", "_ddp_overlap_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DDP_OVERLAP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
