@@ -99,7 +99,8 @@ struct rnampnn_ctx {
     long long prof_n = 0, prof_n_kind[2] = {0, 0};
     // tapes of rnampnn_train_forward calls whose backward may still come (the activations themselves live in the caller's
     // workspaces): one record per workspace, identified by a monotonically increasing id that rnampnn_train_backward must present
-    struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; const unsigned long long* seed_dev; };
+    struct Tape { int64_t id; int B, T, tnorm; float p; uint64_t seed; const void* ws; bool mixed; const unsigned long long* seed_dev;
+                  bool att_mfma; };     // att_mfma: which attention kernels wrote the (m, l) statistics of this tape - the backward must recompute S with the same ones
     std::vector<Tape> tapes;
     int64_t tape_counter = 0;
     // optional: events the backward records on its stream once a chunk of the flat gradient is final (rnampnn_grad_chunks),
