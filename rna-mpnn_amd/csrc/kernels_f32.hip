@@ -5,6 +5,7 @@
 // the graph / geometry / normalisation / decode kernels here serve both precisions.
 // Reference lines restated by each kernel are cited at its head.
 #include "rnampnn_internal.h"
+#include <cstdlib>
 
 #define WAVE 64
 static constexpr float kLEPS = 1.0e6f;
@@ -96,8 +97,15 @@ __global__ void k_zero_bytes(uint4* __restrict__ p, size_t n16, unsigned char* _
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
-void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s) {       // ptr 16-byte aligned
+// RNAMPNN_DBG_MEMNODE (diagnostic, read per call): bit 0 routes launch_zero_bytes through hipMemsetAsync, bit 1 launch_copy_bytes through
+// hipMemcpyAsync - the forms round 3 replaced - so that the captured training step can be compared with and without runtime memset / copy nodes
+// RNAMPNN_DBG_MEMNODE_SITES: bit mask of the launch_zero_bytes call sites (1 row zeroes of the taped forward, 2 flat gradient, 4 dE, 8 reverse-
+// adjacency counts) that take the runtime path; default all
+static int dbg_memnode() { const char* e = getenv("RNAMPNN_DBG_MEMNODE"); return e ? atoi(e) : 0; }
+static int dbg_memnode_sites() { const char* e = getenv("RNAMPNN_DBG_MEMNODE_SITES"); return e ? atoi(e) : 0xff; }
+void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s, int site) {       // ptr 16-byte aligned
     if (!bytes) return;
+    if ((dbg_memnode() & 1) && (dbg_memnode_sites() & site)) { (void)hipMemsetAsync(ptr, 0, bytes, s); return; }
     const size_t n16 = bytes / 16;
     size_t g = (n16 + 255) / 256;
     if (g > 2048) g = 2048;
@@ -111,6 +119,7 @@ __global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst,
 void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {       // both 16-byte aligned, bytes a multiple of 16
     const size_t n16 = bytes / 16;
     if (!n16) return;
+    if (dbg_memnode() & 2) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); return; }
     size_t g = (n16 + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);

@@ -466,7 +466,7 @@ __global__ void k_rev_rank(PackInfo pk, const int* __restrict__ nbr, const int* 
     }
 }
 void t_build_reverse(const PackInfo& pk, int k, const int* nbr, int* deg, int* start, int* fill, int* list, int* tmp, hipStream_t s) {
-    launch_zero_bytes(deg, (size_t)pk.Nmax * sizeof(int), s);
+    launch_zero_bytes(deg, (size_t)pk.Nmax * sizeof(int), s, 8);
     size_t E = (size_t)pk.Nmax * k;
     unsigned g = (unsigned)((E + 255) / 256); if (g > 8192) g = 8192; if (g < 1) g = 1;
     hipLaunchKernelGGL(k_rev_count, dim3(g), dim3(256), 0, s, pk, k, nbr, deg);

@@ -55,7 +55,7 @@ struct PackInfo {            // device arrays describing the packed batch
 // ---- kernels_f32.hip -------------------------------------------------------------------
 struct ZeroRegions { void* ptr[8]; unsigned words[8]; int n; };       // 4-byte aligned regions, sizes in 32-bit words
 void launch_zero_regions(const ZeroRegions& z, hipStream_t s);
-void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s);                    // kernel, not a memset node (hipGraph-safe); ptr 16-byte aligned
+void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s, int site = 0x80);                    // kernel, not a memset node (hipGraph-safe); ptr 16-byte aligned
 void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // kernel copy, 16-byte aligned, bytes % 16 == 0
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s);
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s);

@@ -107,3 +107,19 @@ def test_collate_and_separate_contract():
     flat = torch.arange(8.)
     sep = separate(flat, torch.tensor([3, 5]))
     assert sep.tolist() == [[0, 1, 2, 0, 0], [3, 4, 5, 6, 7]]
+
+
+def test_training_path_issues_no_runtime_memset():
+    """Round 4 (profiles/r04_graph_memset_root_cause.txt): a hipMemsetAsync captured by torch.cuda.CUDAGraph zeroes on the first replay and
+    writes garbage from the second one on (this stack), which corrupted the captured training step in round 3.  The sources of the training
+    path therefore zero and copy with their own kernels (launch_zero_bytes / launch_copy_bytes); the only runtime memsets left are in eager
+    set-up code and a test tap that are never captured."""
+    import re
+    csrc = os.path.join(REPO, "rna-mpnn_amd", "csrc")
+    for name in ("kernels_train.hip", "kernels_train.h"):
+        src = open(os.path.join(csrc, name)).read()
+        assert "hipMemsetAsync" not in src and "hipMemset(" not in src, name
+    inc = open(os.path.join(csrc, "train.inc")).read()
+    body = inc[:inc.index("rnampnn_edge_raw_features")] if "rnampnn_edge_raw_features" in inc else inc
+    assert "hipMemsetAsync" not in body, "train.inc: a runtime memset inside the (capturable) training entry points"
+    assert len(re.findall(r"launch_zero_bytes\(", body)) >= 4
