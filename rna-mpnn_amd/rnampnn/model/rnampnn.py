@@ -125,6 +125,27 @@ class RNAMPNN(NativeModule):
             pick["ws"] = torch.empty(need, dtype=torch.uint8, device=device)
         return pick, (_TapeLease(pick) if lease else None)
 
+    def reserve_training(self, shapes) -> None:
+        """Size the training workspace for the largest of ``shapes`` = iterable of (B, T) BEFORE a timed loop: the pool grows on demand, and
+        growing a multi-gigabyte tape in the middle of an epoch (free + allocate + the allocator's synchronisation) costs tens of
+        milliseconds each time - the batch shapes of a jittered epoch plan differ from epoch to epoch."""
+        device = self._ensure(for_mixed_training=self.train_precision == "bf16")
+        best, need_max = None, 0
+        for B, T in shapes:
+            need = int(_native.lib().rnampnn_train_workspace_bytes(self._handle.ptr, int(B), int(T)))
+            if need > need_max:
+                best, need_max = (int(B), int(T)), need
+        if best is None:
+            return
+        pool = self.__dict__.setdefault("_tape_pool", [])
+        have = max((slot["ws"].numel() for slot in pool if not slot["busy"] and slot["ws"].device == device), default=0)
+        if have < need_max + 256:
+            for slot in pool:                       # drop the idle smaller ones first: one big tape, not two
+                if not slot["busy"] and slot["ws"].device == device:
+                    slot["ws"] = torch.empty(0, dtype=torch.uint8, device=device)
+            pool[:] = [slot for slot in pool if slot["busy"] or slot["ws"].numel() > 0]
+            pool.append({"ws": torch.empty(int(need_max * 1.05) + 256, dtype=torch.uint8, device=device), "busy": False})
+
     @staticmethod
     def _ws_ptr(slot):
         base = slot["ws"].data_ptr()

@@ -89,6 +89,8 @@ class Trainer:
         self.model.train()
         mine, t_glob = plan_epoch(lengths, self.rank, self.world, batch_size, max_rows, self.seed + epoch)
         loader = PaddedLoader(items, mine, device=self.device)
+        # (the jittered plan has other batch shapes in every epoch: size the tape for this epoch's largest step before the clock starts)
+        self.model.reserve_training((len(b), max(int(lengths[i]) for i in b)) for b in mine)
         self._loss.zero_()
         torch.cuda.synchronize(self.device)
         t0 = time.perf_counter()
