@@ -12,6 +12,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 static constexpr float kSEPS = 1.0e-6f;
+#define RN_E_F16 1                // the edge tensor e is stored as f16 of a e (bf16 in rounds 1 - 2)
+#define RN_P_F16 1                // the P / Q tables are f16
+#define RN_PHI_DEG 4              // coefficients of Phi's polynomial in the per-edge kernels
 
 __device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(bf16_t, (__bf16)x); }   // RNE, NaN kept
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
@@ -23,9 +26,6 @@ __device__ __forceinline__ float lo_bf(unsigned w) { return __uint_as_float(w <<
 __device__ __forceinline__ float hi_bf(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef RN_EXP_NOMFMA
-    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
-#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -34,16 +34,10 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 // monotone argument, so no clamp: 7 VALU instructions, 2 of them transcendental.
 // The f32 path and the node-level GEMM epilogues keep erff().
 __device__ __forceinline__ float gelu_fast(float x) {
-#ifdef RN_GELU_ABS      // experiment: exponent x (c0 + c1 |x|): one instruction fewer, max |err| 2.3e-3
-    float p = fmaf(__builtin_fabsf(x), -0.29175830f, -2.1208189f);
-    float ex = __builtin_amdgcn_exp2f(x * p);
-    return x * __builtin_amdgcn_rcpf(1.0f + ex);
-#else
     float t = x * x;
     float p = fmaf(t, -0.10012571f, -2.3087657f);          // -log2(e) * (c0 + c1 t), c0 = 1.60031416, c1 = 0.06940179
     float ex = __builtin_amdgcn_exp2f(x * p);              // exp(-x (c0 + c1 t))
     return x * __builtin_amdgcn_rcpf(1.0f + ex);
-#endif
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -54,9 +48,6 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // Hidden activations then stay in f16 (11-bit significand, finer than the bf16 they replace) and feed
 // v_mfma_f32_32x32x16_f16; where the result is consumed in f32 (residual, mean) the final x * Phi is a mixed-precision
 // FMA on the f32 accumulator, so only Phi itself is rounded to f16.
-#ifndef RN_PHI_DEG
-#define RN_PHI_DEG 4              // number of coefficients of q
-#endif
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 __device__ __forceinline__ f16x2 cvt_h2(float a, float b) {          // one v_cvt_pk_f16_f32 (RNE)
@@ -65,18 +56,10 @@ __device__ __forceinline__ f16x2 cvt_h2(float a, float b) {          // one v_cv
 }
 __device__ __forceinline__ f16x2 h2(float v) { return f16x2{(_Float16)v, (_Float16)v}; }
 __device__ __forceinline__ f16x2 phi2(f16x2 x) {
-#if RN_PHI_DEG == 4      // max |x Phi - gelu| 3.1e-3 in exact arithmetic
     f16x2 s = __builtin_elementwise_min(x * x, h2(9.5f));
     f16x2 q = __builtin_elementwise_fma(s, h2(-0.00017380498f), h2(0.0048129941f));
     q = __builtin_elementwise_fma(q, s, h2(-0.05394074f));
     q = __builtin_elementwise_fma(q, s, h2(0.38869277f));
-#else                    // 5 coefficients in s/4 (keeps every coefficient a normal f16): 1.2e-3
-    f16x2 s = __builtin_elementwise_min(x * (x * h2(0.25f)), h2(11.5f * 0.25f));
-    f16x2 q = __builtin_elementwise_fma(s, h2(1.066712254e-05f * 256.f), h2(-0.00041787775f * 64.f));
-    q = __builtin_elementwise_fma(q, s, h2(0.00673485407f * 16.f));
-    q = __builtin_elementwise_fma(q, s, h2(-0.05988154784f * 4.f));
-    q = __builtin_elementwise_fma(q, s, h2(0.39435085475f));
-#endif
     f16x2 p = __builtin_elementwise_fma(x, q, h2(0.5f));
     return __builtin_elementwise_min(__builtin_elementwise_max(p, h2(0.f)), h2(1.f));
 }
@@ -93,18 +76,10 @@ __device__ __forceinline__ f16x4 cvt_h4(float a, float b, float c, float d) {
     return __builtin_convertvector(v, f16x4);
 }
 __device__ __forceinline__ f16x4 phi4(f16x4 x) {
-#if RN_PHI_DEG == 4
     f16x4 s = __builtin_elementwise_min(x * x, h4(9.5f));
     f16x4 q = __builtin_elementwise_fma(s, h4(-0.00017380498f), h4(0.0048129941f));
     q = __builtin_elementwise_fma(q, s, h4(-0.05394074f));
     q = __builtin_elementwise_fma(q, s, h4(0.38869277f));
-#else
-    f16x4 s = __builtin_elementwise_min(x * (x * h4(0.25f)), h4(11.5f * 0.25f));
-    f16x4 q = __builtin_elementwise_fma(s, h4(1.066712254e-05f * 256.f), h4(-0.00041787775f * 64.f));
-    q = __builtin_elementwise_fma(q, s, h4(0.00673485407f * 16.f));
-    q = __builtin_elementwise_fma(q, s, h4(-0.05988154784f * 4.f));
-    q = __builtin_elementwise_fma(q, s, h4(0.39435085475f));
-#endif
     f16x4 p = __builtin_elementwise_fma(x, q, h4(0.5f));
     return __builtin_elementwise_min(__builtin_elementwise_max(p, h4(0.f)), h4(1.f));
 }
@@ -175,9 +150,7 @@ __device__ __forceinline__ void stage_image(u32x4* __restrict__ dst, const u32x4
 // The same copy by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, every piece of a thread in flight at once; a wave's
 // piece is 1 KiB: wave-uniform LDS base, the DMA adds lane * 16).  The caller waits with s_waitcnt vmcnt(0) + a workgroup barrier
 // before the first read (the compiler does not know these loads write LDS).  TOTAL: 16-byte units, whole waves per piece.
-#ifndef RN_NO_DMA_STAGE
 #define RN_DMA_STAGE 1
-#endif
 template <int NT, int TOTAL = 4096>
 __device__ __forceinline__ void stage_image_dma(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int tid) {
     static_assert(TOTAL % 64 == 0 && NT % 64 == 0, "whole waves per DMA piece");
@@ -208,9 +181,6 @@ __device__ __forceinline__ float fma_mix_hi(float a, f16x2 hp, float c) {
     return d;
 }
 __device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef RN_EXP_NOMFMA
-    c[0] += __uint_as_float(a[0] ^ b[0]); return c;
-#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // Storage format of the per-edge tensor e of this path (fragment-major, see efrag_ptr): f16 of a e.  |a e| stays far inside the f16 range,
@@ -218,9 +188,6 @@ __device__ __forceinline__ f32x16 mfma32h(u32x4 a, u32x4 b, f32x16 c) {
 // the fragment words as loaded (bf16 storage cost an unpack, an f32 mixed fma and a repack per element: 10 vector instructions per four
 // elements against 2, 128 of the ~1,460 a block issues), and the products e . Wc run as f16 MFMAs on the words as loaded.
 // RN_E_F16=0 builds the bf16-storage form (A/B).
-#ifndef RN_E_F16
-#define RN_E_F16 1
-#endif
 __device__ __forceinline__ bf16_t e_enc(float x) { return RN_E_F16 ? __builtin_bit_cast(bf16_t, (_Float16)x) : f2bf(x); }
 __device__ __forceinline__ float e_dec(bf16_t v) { return RN_E_F16 ? (float)__builtin_bit_cast(_Float16, v) : bf2f(v); }
 __device__ __forceinline__ f32x16 mfma_e(u32x4 a, u32x4 b, f32x16 c) { return RN_E_F16 ? mfma32h(a, b, c) : mfma32(a, b, c); }
@@ -228,9 +195,6 @@ __device__ __forceinline__ f32x16 mfma_e(u32x4 a, u32x4 b, f32x16 c) { return RN
 // (hi, lo) bf16 words of rounds 1-2 (entry 32 mb + m <-> accumulator row m of channel block mb).  The injection MFMA then is an f16 product of
 // (P, 0) against (1, 1); 11 significand bits against the 8 of the gathered Q rows beside it.  Halves the P bytes k_node_update writes (it is
 // HBM-bound on its table writes) and the fused kernel reads.  RN_P_F16=0 builds the word form (A/B).
-#ifndef RN_P_F16
-#define RN_P_F16 1
-#endif
 __device__ __forceinline__ unsigned p_pack2(float a, float b) {       // two P entries -> one word of two f16
     f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));

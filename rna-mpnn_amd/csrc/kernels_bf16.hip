@@ -232,11 +232,6 @@ __device__ __forceinline__ void gelu_pack(const f32x16& acc, u32x4& lo, u32x4& h
 //            h + agg of mpnn.py:222 is taken by the graph-norm kernel that follows)
 // One wave owns one block: lanes (r, h) = (edge r of the block, k-half h).  k <= 16 packs
 // npb = 32/k residues into a block (edges of consecutive residues are contiguous in e).
-#ifdef RN_STAMPS   // diagnostic build only: per-phase cycle shares of the fused kernel (never shipped enabled)
-#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(var) do { } while (0)
-#endif
 struct NodeTabs {             // per-residue parts of the first Linears (k_node_update outputs): f16 of a P / a Q, natural channel order
     const bf16_t* p_e;        // [N+1][128] f16  P = h.Wa_e^T + b1_e
     const bf16_t* q_e;        // [N+1][128] f16  h.Wb_e^T         (row N = zeros)
@@ -244,7 +239,6 @@ struct NodeTabs {             // per-residue parts of the first Linears (k_node_
     const bf16_t* q_m;
     const float* h_res;       // [N][128] f32 or null: the residue's h, added to the mean so that the launch writes h + agg (mpnn.py:222): the
                               // statistics and update kernels behind it then read ONE node tensor instead of two
-    unsigned long long* dbg;  // RN_STAMPS diagnostic buffer (null otherwise)
 };
 
 #ifndef RN_MPNN_WAVES
@@ -317,23 +311,16 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         const int b0 = blk < blk_end ? blk : 0;
         const int i0 = b0 * npb * k + r;
         jraw_first = nbr[i0 > last_idx ? last_idx : i0];
-#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOELOAD)
 #pragma unroll
         for (int s = 0; s < 8; ++s) ef[s] = efrag_ptr(e, b0, lane)[64 * s];
-#endif
         if (!SMALLK) {
             if (DO_EDGE) pn_e[0] = reinterpret_cast<const unsigned*>(tab.p_e + (size_t)b0 * RN_D)[lane];
             if (DO_MSG) pn_m[0] = reinterpret_cast<const unsigned*>(tab.p_m + (size_t)b0 * RN_D)[lane];
             if (DO_MSG && tab.h_res) hn = *reinterpret_cast<const f32x2*>(tab.h_res + (size_t)b0 * RN_D + 2 * lane);
         }
     }
-#ifdef RN_DMA_STAGE
     if (DO_EDGE) stage_image_dma<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
     if (DO_MSG) stage_image_dma<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
-#else
-    if (DO_EDGE) stage_image<NW * 64>(img_e, reinterpret_cast<const u32x4*>(we.img), tid);
-    if (DO_MSG) stage_image<NW * 64>(img_m, reinterpret_cast<const u32x4*>(wm.img), tid);
-#endif
     if (tid < 128) {
         // The gathered Q row (bf16, fetched in the e-fragment layout: q[s] = channels 16s+8h..) is added by the MATRIX
         // pipe: two extra MFMAs per channel block whose A operand is the constant 0/1 matrix that routes channel
@@ -366,14 +353,9 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             lds_gb[32 * blk4 + rr] = bs * (float)phi2s(cvt_h2(bs, bs))[0];      // (bs = a b2: wm.b2p is stored scaled)
         }
     }
-#ifdef RN_DMA_STAGE
     dma_landed();          // (the first block's e / P / index loads issued above have landed too: they are needed right after the barrier)
-#endif
     __syncthreads();
 
-#ifdef RN_EXP_SETPRIO      /* experiment: static priority for the second-dispatched half of the workgroup (MI355X guide, two waves per SIMD, item 4) */
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     const u32x4 perm0 = lds_perm[lane], perm1 = lds_perm[64 + lane];
     const u32x4 perm0e = EDGE1 ? lds_perm[128 + lane] : perm0, perm1e = EDGE1 ? lds_perm[192 + lane] : perm1;   // routing of the edge MLP's Q
     const u32x4 ones_a = {ones_w, 0u, 0u, 0u};
@@ -395,14 +377,10 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
     int j;                                             // packed neighbour row of this lane's edge, -1: no edge
     // ---- block state: everything a block needs from HBM (addresses clamped, loads unconditional)
     auto load_e = [&](int b, int s) {
-#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOELOAD)
         ef[s] = efrag_ptr(e, b, lane)[64 * s];
-#endif
     };
     auto gather_q = [&](u32x4 (&dst)[8], const bf16_t* table, int row, int s) {
-#ifndef RN_EXP_NOQ
         dst[s] = (reinterpret_cast<const u32x4*>(table + (size_t)row * RN_D) + h)[2 * s];
-#endif
     };
     auto load_p = [&](int b) {                         // !SMALLK: the residue's P words (coalesced 512 B rows), requested early ...
         if (SMALLK) return;
@@ -450,10 +428,6 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         constexpr int c = decltype(cc)::value, i = decltype(ii)::value;
         constexpr int kind = c >> 2, cb = c & 3;       // kind 0: E1, 1: E2, 2: M1, 3: M2
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef RN_EXP_NOHELP      /* ablation: no injection / routing MFMAs (wrong results) */
-        if constexpr (i == 0) { T = z; return; }
-        if constexpr (i > 8) return;
-#endif
         if constexpr (i == 0) {
             if constexpr (kind == 0) inject_p(T, tab.p_e, pwe[cb], cb, EDGE1);
             else if constexpr (kind == 2) inject_p(T, tab.p_m, pwm[cb], cb, false);
@@ -464,9 +438,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
             if constexpr (kind == 0 || kind == 2) T = mfma_e(wf[s], ef[s], T);
             else if constexpr (kind == 1) T = mfma32h(wf[s], hb[s], T);
             else T = mfma32h(hb[s], wf[s], T);
-#ifndef RN_EXP_NOLDS
             wf[s] = RN_FRAG(RN_NEXT(c), s);            // the register is free again: request the next chain's fragment
-#endif
             if constexpr (i == 4) {
                 constexpr int cn = RN_NEXT(c), kn = cn >> 2;
                 if constexpr (kn == 1) bwn = lds_bwe[(cn & 3) * 64 + lane];
@@ -492,15 +464,6 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         constexpr bool resid = kind == 1 || (EDGE1 && kind == 0);     // this chain's output is added to e
         constexpr int gpq = (kind == 3 || (resid && !RN_E_F16)) ? 3 : 2;   // granules per quarter (f16 e: the residual add is two instructions of granule B)
         constexpr int v = g / gpq, ph = g % gpq;
-#ifdef RN_EXP_NOGELU
-        if constexpr (ph == 0) { gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]); gq = gx; }
-        else if constexpr (ph == 1) {
-            if constexpr (kind == 0 || kind == 2) {
-                hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gx));
-                hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gx));
-            }
-        } else
-#endif
         if constexpr (ph == 0) {
             gx = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
             gs = clamp01h(gx * gx);                    // (scaled domain: the clamp is the multiply's output modifier)
@@ -515,25 +478,19 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
                 hb[2 * cb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(gv));
                 hb[2 * cb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(gv));
             }
-#if RN_E_F16
             if constexpr (resid) {                     // e <- e + GELU(.): e is f16 as stored, x Phi + e is one packed fma per fragment word
                 constexpr int sp = v >> 1, t = 2 * (v & 1);
                 const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
                 ef[2 * cb + sp][t] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(lo2(gx), lo2(gq), __builtin_bit_cast(f16x2, o0)));
                 ef[2 * cb + sp][t + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(hi2(gx), hi2(gq), __builtin_bit_cast(f16x2, o1)));
-#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
                 if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
-#endif
             }
-#endif
         } else if constexpr (resid) {                  // (bf16 storage) e <- e + GELU(.), registers 8sp + 2t.. <-> ef[2ob + sp][t]
             constexpr int sp = v >> 1, t = 2 * (v & 1);
             const unsigned o0 = ef[2 * cb + sp][t], o1 = ef[2 * cb + sp][t + 1];
             ef[2 * cb + sp][t] = pack2(fma_mix_lo(T[4 * v], lo2(gq), lo_bf(o0)), fma_mix_hi(T[4 * v + 1], lo2(gq), hi_bf(o0)));
             ef[2 * cb + sp][t + 1] = pack2(fma_mix_lo(T[4 * v + 2], hi2(gq), lo_bf(o1)), fma_mix_hi(T[4 * v + 3], hi2(gq), hi_bf(o1)));
-#if !defined(RN_EXP_NOE) && !defined(RN_EXP_NOESTORE)
             if constexpr (v & 1) efrag_ptr(e, gblk, lane)[64 * (2 * cb + sp)] = ef[2 * cb + sp];
-#endif
         } else if constexpr (!SMALLK && !MSGOUT) {     // mean over the real edges of the residue
             // every one of the 32 rows is summed unmasked; rows of absent edges hold GELU(bias) exactly and are taken out again
             if constexpr (v == 0) { s0 = 0.f; s1 = 0.f; gbv = lds_gb[32 * cb + r]; }
@@ -620,11 +577,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #define RN_NOEXTRA(i) do { } while (0)
 
     RN_SLOT(C_FIRST, C_FIRST, false, RN_NOEXTRA);      // first chain of the first block: nothing to overlap with yet
-#ifdef RN_STAMPS
-    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
-#endif
     while (true) {
-        STAMP(t0);
         const int nblk = blk + stride;
         const bool has_next = nblk < blk_end;
         const int nb_c = has_next ? nblk : blk;        // the last iteration re-reads its own block (results unused)
@@ -655,21 +608,16 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
 #define RN_EXTRA_QM(i) do { if constexpr ((i) >= 1 && (i) <= 8 && DO_MSG) gather_q(q, tab.q_m, RN_QROW(j), (i) - 1); } while (0)
         if constexpr (DO_EDGE) {
             RN_SLOT(1, 0, true, RN_NOEXTRA); RN_SLOT(2, 1, true, RN_NOEXTRA); RN_SLOT(3, 2, true, RN_NOEXTRA);
-            STAMP(t1);
             if constexpr (!EDGE1) {
                 RN_SLOT(4, 3, true, RN_EXTRA_QM); RN_SLOT(5, 4, true, RN_NOEXTRA); RN_SLOT(6, 5, true, RN_NOEXTRA); RN_SLOT(7, 6, true, RN_NOEXTRA);
             }
-            STAMP(t2);
         }
         if constexpr (DO_EDGE && DO_MSG && !EDGE1) RN_SLOT(8, 7, true, RN_NOEXTRA);
         if constexpr (DO_EDGE && DO_MSG && EDGE1) RN_SLOT(8, 3, true, RN_EXTRA_QM);    // (the message MLP's Q rows are requested at its own first chain)
         if constexpr (DO_MSG) {
                         RN_SLOT(9, 8, true, RN_NOEXTRA); RN_SLOT(10, 9, true, RN_NOEXTRA); RN_SLOT(11, 10, true, RN_EXTRA_E);
-            STAMP(t3);
             RN_SLOT(12, 11, true, RN_EXTRA_N0); RN_SLOT(13, 12, true, RN_EXTRA_N1);
-            STAMP(t4);
             RN_SLOT(14, 13, true, RN_EXTRA_N2); RN_SLOT(15, 14, true, RN_EXTRA_N3);
-            STAMP(t5);
         } else {
             // edge update only (stand-alone API): the last epilogue rewrites e, so the next block's state cannot be requested early
             static_for<RN_NGRAN(C_LAST)>([&](auto gg) { epi_granule(std::integral_constant<int, C_LAST>{}, gg, RN_TILE(C_LAST), gblk, gvmask, gcntf, ginv); });
@@ -687,16 +635,7 @@ __global__ void __launch_bounds__(RN_MPNN_WAVES * 64, RN_MPNN_WAVES / 4) k_mpnn_
         RN_FENCE();
         if constexpr (DO_MSG) RN_SLOT(C_FIRST, 15, true, RN_NOEXTRA);      // first chain of the next block || last epilogue of this one
         else RN_SLOT(C_FIRST, C_FIRST, false, RN_NOEXTRA);
-#ifdef RN_STAMPS
-        STAMP(t6);
-        phase[0] += t1 - t0; phase[1] += t2 - t1; phase[2] += t3 - t2; phase[3] += t4 - t3; phase[4] += t5 - t4; phase[5] += t6 - t5;
-        phase[6] += t6 - t0; phase[7] += 1;
-#endif
     }
-#ifdef RN_STAMPS
-    if (tab.dbg && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(tab.dbg + i, phase[i]);
-#endif
     if constexpr (DO_MSG) static_for<RN_NGRAN(15)>([&](auto gg) { epi_granule(std::integral_constant<int, 15>{}, gg, RN_TILE(15), gblk, gvmask, gcntf, ginv); });
 #undef RN_EXTRA_QM
 #undef RN_EXTRA_N3
@@ -732,13 +671,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     if (grid > num_cus()) grid = num_cus();
     if (grid < 1) grid = 1;
     size_t lds = RN_MPNN_LDS;
-    NodeTabs tab{p_e, q_e, p_m, q_m, h_res, nullptr};
-#ifdef RN_STAMPS
-    static unsigned long long* dbg = nullptr;
-    if (!dbg) (void)hipMalloc((void**)&dbg, 64);
-    (void)hipMemsetAsync(dbg, 0, 64, s);
-    tab.dbg = dbg;
-#endif
+    NodeTabs tab{p_e, q_e, p_m, q_m, h_res};
     const bool smallk = k <= 16, mo = msg_out != nullptr;
 #define RN_LAUNCH(E, M, S, O, E1)                                                                              \
     do {                                                                                                       \
@@ -753,16 +686,6 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
     else if (mo)           { if (smallk) RN_LAUNCH(false, true, true, true, false); else RN_LAUNCH(false, true, false, true, false); }
     else                   { if (smallk) RN_LAUNCH(false, true, true, false, false); else RN_LAUNCH(false, true, false, false, false); }
 #undef RN_LAUNCH
-#ifdef RN_STAMPS
-    unsigned long long hst[8];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(hst, dbg, 64, hipMemcpyDeviceToHost);
-    if (hst[7]) {
-        fprintf(stderr, "[stamps e=%d m=%d] blocks %llu cycles/block: slots 1-3 %.0f | 4-7 %.0f | 8-11 %.0f | 12-13 %.0f | 14-15 %.0f | next 0 %.0f | total %.0f\n",
-                (int)do_edge, (int)do_msg, hst[7], (double)hst[0] / hst[7], (double)hst[1] / hst[7], (double)hst[2] / hst[7],
-                (double)hst[3] / hst[7], (double)hst[4] / hst[7], (double)hst[5] / hst[7], (double)hst[6] / hst[7]);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,11 +699,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
 //   * the loop is software-pipelined on its only dependent memory chain: the neighbour index of block i+2 and the
 //     neighbour record of block i+1 are requested while block i runs through the matrix pipe;
 //   * no divergent branch: validity is an AND mask on the packed output words.
-#ifdef RN_EE_NOFENCE
-#define RN_EE_FENCE() do { } while (0)
-#else
 #define RN_EE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 #ifndef EE_WAVES
 #define EE_WAVES 8                // waves per workgroup; two workgroups (61 KiB of LDS each) per CU
 #endif
@@ -828,9 +747,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
     int blk = blockIdx.x * EE_WAVES + wave;
     if (blk >= nblocks) return;
     int j_cur = load_j(blk), j_nxt = load_j(blk + stride);
-#ifndef EE_NOPREFETCH
     load_rec(j_cur);
-#endif
 
     for (; blk < nblocks; blk += stride) {
         // ---- central record: wave-uniform pointer (k > 16) -> scalar loads; per-lane pointer otherwise
@@ -839,9 +756,6 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
         auto catom = [&](int a, int d) { return a < 4 ? gc[3 * a + d] : gc[32 + 3 * (a - 4) + d]; };
         auto cbond = [&](int a, int d) { return a < 3 ? gc[12 + 3 * a + d] : gc[32 + 12 + 3 * (a - 3) + d]; };
         auto cnorm = [&](int a, int d) { return a < 2 ? gc[21 + 3 * a + d] : gc[32 + 21 + 3 * (a - 2) + d]; };
-#ifdef EE_NOPREFETCH
-        load_rec(j_cur);
-#endif
         float nl[28];
 #pragma unroll
         for (int v = 0; v < 7; ++v) { nl[4 * v] = nrec[v][0]; nl[4 * v + 1] = nrec[v][1]; nl[4 * v + 2] = nrec[v][2]; nl[4 * v + 3] = nrec[v][3]; }
@@ -877,9 +791,7 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
         RN_EE_FENCE();
         // ---- requests of the next two blocks (their latency passes under this block's matrix work)
         const unsigned vmask = j_cur >= 0 ? 0xffffffffu : 0u;
-#ifndef EE_NOPREFETCH
         load_rec(j_nxt);
-#endif
         j_cur = j_nxt;
         j_nxt = load_j(blk + 2 * stride);
         RN_EE_FENCE();
@@ -910,16 +822,10 @@ __global__ void __launch_bounds__(EE_WAVES * 64, EE_WAVES / 2) k_edge_embed_bf16
                 u32x4 nw;
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
-#if RN_E_F16
                     const f16x4 xq = cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]);
                     const f16x4 gq4 = xq * phi4s(xq);
                     nw[t] = __builtin_bit_cast(unsigned, lo2(gq4)) & vmask;
                     nw[t + 1] = __builtin_bit_cast(unsigned, hi2(gq4)) & vmask;
-#else
-                    const f16x4 ph = phi4s(cvt_h4(acc[8 * sp + 2 * t], acc[8 * sp + 2 * t + 1], acc[8 * sp + 2 * t + 2], acc[8 * sp + 2 * t + 3]));
-                    nw[t] = pack2(fma_mix_lo(acc[8 * sp + 2 * t], lo2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 1], lo2(ph), 0.f)) & vmask;
-                    nw[t + 1] = pack2(fma_mix_lo(acc[8 * sp + 2 * t + 2], hi2(ph), 0.f), fma_mix_hi(acc[8 * sp + 2 * t + 3], hi2(ph), 0.f)) & vmask;
-#endif
                 }
                 ewp[64 * (2 * ob + sp)] = nw;
             }
@@ -1099,24 +1005,12 @@ __device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4
 // one of the 8 DMA pieces of chunk c (issued between the MFMAs of the chunk that runs three chunks earlier: the ~100
 // cycles a DMA holds the wave's issue then pass under a busy matrix pipe instead of in front of it)
 __device__ __forceinline__ void chain_issue_piece(const u32x4* __restrict__ img, u32x4* ring, int c, int tid, int i) {
-#ifdef CH_EXP_NODMA       /* ablation: the weight stream stops after the prologue's three chunks (wrong results) */
-    return;
-#endif
     const u32x4* src = img + (size_t)c * 2048 + tid + i * 256;
     u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63) + i * 256;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 __device__ __forceinline__ void chain_wait(int chunks_after) {       // folded to one s_waitcnt after unrolling
-#ifdef CH_EXP_NODMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); return;
-#endif
-#ifdef CH_EXP_NOBARRIER   /* ablation: waves do not wait for each other's DMA pieces (wrong results) */
-    if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-#endif
     if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1139,9 +1033,6 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
     auto granule = [&](const f32x16& acc, auto obc, auto tc) {
         constexpr int ob = decltype(obc)::value, t = decltype(tc)::value;
         if constexpr (!LAST) {
-#ifdef CH_EXP_NOGELU
-            const f16x4 g = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
-#else
 #if CH_GELU == 2           /* experiment: f32 sigmoid-form GELU (2.7e-4) */
             const f16x4 g = cvt_h4(gelu_fast(acc[2 * t]), gelu_fast(acc[2 * t + 1]), gelu_fast(acc[8 + 2 * t]), gelu_fast(acc[8 + 2 * t + 1]));
 #else
@@ -1150,7 +1041,6 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
             const f16x4 g = x * phi4_hi(x);        // packed-f16 GELU, five-coefficient Phi (1.2e-3): what follows a node chain is a GraphNormalization
 #else
             const f16x4 g = x * phi4(x);           // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
-#endif
 #endif
 #endif
             out[2 * ob][t] = __builtin_bit_cast(unsigned, lo2(g));
@@ -1175,14 +1065,9 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
             acc = init_vec16(bias_lds + 32 * ob + 16 * h);
             static_for<NKS>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value, m = o * NKS + ks;      // m: MFMA number within the chunk (32 per chunk)
-#ifdef CH_EXP_NOMFMA      /* ablation: no matrix work (wrong results) */
-                acc[0] += __uint_as_float(fr[m & 7][0] ^ in[ks][0]);
-#else
                 acc = mfma32h(fr[m & 7], in[ks], acc);    // f16 operands in every layer
-#endif
                 if constexpr (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
                 if constexpr (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
-#ifndef CH_NO_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ob > 0) {                        // granules of the previous block behind this block's MFMAs
                     if constexpr (NKS >= 4) {
@@ -1194,18 +1079,11 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
             });
-#ifdef CH_NO_INTERLEAVE
-            static_for<4>([&](auto tc) { granule(acc, std::integral_constant<int, ob>{}, tc); });
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         });
     });
-#ifndef CH_NO_INTERLEAVE
     static_for<4>([&](auto tc) { granule(((NOB - 1) & 1) ? accB : accA, std::integral_constant<int, NOB - 1>{}, tc); });
     __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 template <int K0, int H, int NH, int NOUT>
@@ -1428,13 +1306,6 @@ __global__ void __launch_bounds__(256) k_gn_coef(PackInfo pk, const float* __res
     }
 }
 
-#ifdef NU_STAMPS      // diagnostic build only: per-phase clock of workgroups 0 / 100 / 239 (never shipped enabled)
-__device__ unsigned long long nu_dbg[3][8];
-#define NU_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 239)) \
-    nu_dbg[blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : 2)][i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define NU_STAMP(i) do { } while (0)
-#endif
 typedef NodeJob PqJob;     // img: [8 ob][8 ks][64][8]; ob < 4 -> P rows, >= 4 -> Q rows
 
 template <int NJOBS>
@@ -1449,7 +1320,6 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     const int row = row_blk + 32 * wave + r;
     const bool ok = row < ntot;
     const int rr = ok ? row : 0;
-    NU_STAMP(0);
     const float* cf = coef + (size_t)pk.node_b[rr] * 256;
     // the HBM loads of the rows go out first; the weight images (L2-resident) are staged into LDS while they fly
     f32x4 vx[8][2], va[8][2];
@@ -1464,13 +1334,8 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef RN_DMA_STAGE
     stage_image_dma<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
     if (NJOBS > 1) stage_image_dma<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
-#else
-    stage_image<256>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
-    if (NJOBS > 1) stage_image<256>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     // the biases of the P halves go through LDS too (a global read per channel block would expose an L2 round trip each)
     float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);
@@ -1490,18 +1355,15 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
         }
     }
-    NU_STAMP(1);
     u32x4 xf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const f32x4 v0 = vx[s][0], v1 = vx[s][1];
         xf[s] = u32x4{p_pack2(v0[0], v0[1]), p_pack2(v0[2], v0[3]), p_pack2(v1[0], v1[1]), p_pack2(v1[2], v1[3])};      // f16 rows, f16 images
     }
-#ifdef RN_DMA_STAGE
     __builtin_amdgcn_sched_barrier(0);
     dma_landed();          // (every row / coefficient load above has been consumed: only the image pieces can still be in flight; the h_out
     __builtin_amdgcn_sched_barrier(0);     //  stores below then drain under the matrix work)
-#endif
     if (ok && h_out) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -1510,9 +1372,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = vx[s][1];
         }
     }
-    NU_STAMP(2);
     __syncthreads();
-    NU_STAMP(3);
 #pragma unroll
     for (int jb = 0; jb < NJOBS; ++jb) {
         const PqJob& jbq = jb == 0 ? j0 : j1;
@@ -1540,9 +1400,7 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    NU_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    NU_STAMP(5);
 }
 
 // [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256].
@@ -1581,16 +1439,6 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     const float* cf = scale ? coef : nullptr;
     if (njobs == 1) hipLaunchKernelGGL(k_node_update<1>, grid, dim3(256), 65536 + 1024, s, pk, x, add, cf, h_out, j0, j1);
     else hipLaunchKernelGGL(k_node_update<2>, grid, dim3(256), 131072 + 1024, s, pk, x, add, cf, h_out, j0, j1);
-#ifdef NU_STAMPS
-    {
-        unsigned long long hst[3][8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(nu_dbg), sizeof(hst));
-        for (int w = 0; w < 3; ++w)
-            fprintf(stderr, "[node update stamps wg %d] start +%llu | rows+coef %llu | pack+hout %llu | barrier %llu | mfma+stores %llu | drain %llu | total %llu\n", w,
-                    hst[w][0] - hst[0][0], hst[w][1] - hst[w][0], hst[w][2] - hst[w][1], hst[w][3] - hst[w][2], hst[w][4] - hst[w][3], hst[w][5] - hst[w][4], hst[w][5] - hst[w][0]);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1742,12 +1590,6 @@ void launch_build_attn_images(const float* wqkv, const float* wout, bf16_t* img_
     hipLaunchKernelGGL(k_build_attn_images, dim3(12 * 8 * 64 * 8 / 256), dim3(256), 0, s, wqkv, wout, img_qkv, img_out);
 }
 #define AL_NW 16
-#ifdef AL_STAMPS      // diagnostic build only: per-phase cycles of workgroup 0 (never shipped enabled)
-__device__ unsigned long long al_dbg[8];
-#define AL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) al_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define AL_STAMP(i) do { } while (0)
-#endif
 __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, float* __restrict__ x, const bf16_t* __restrict__ wqkv,
         const float* __restrict__ bqkv, const bf16_t* __restrict__ wout, const float* __restrict__ bout,
         const float* __restrict__ gscale, const float* __restrict__ gshift, int t_tot) {
@@ -1769,7 +1611,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     float* xb = x + (size_t)base * RN_D;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     // ---- phase 0
-    AL_STAMP(0);
     if (tid < 384) lb[tid] = bqkv[tid];
     else if (tid < 512) lb[tid] = bout[tid - 384];
     for (int t = wave; t < nrb * 8; t += AL_NW) {
@@ -1792,7 +1633,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     const int nt1 = nrb * 12;
     if (wave < nt1) load_wqkv(afa, wave);
     __syncthreads();
-    AL_STAMP(1);
     auto qkv_tile = [&](const u32x4 (&af)[8], int t) {
         const int cb = t / nrb, rb = t - cb * nrb;
         f32x16 acc;
@@ -1834,7 +1674,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     };
     const int nt3 = nrb * 4;
     __syncthreads();
-    AL_STAMP(2);
     // ---- phase 2: tasks (head, query block)
     for (int task = wave; task < 8 * nrb; task += AL_NW) {
         const int hd = task & 7, qb = task >> 3;
@@ -1889,7 +1728,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
     }
     if (wave < nt3) load_wout(afa, wave);           // (in flight across the barrier)
     __syncthreads();
-    AL_STAMP(3);
     // ---- phase 3: y = Wout . O^T + b + x, tiles t = cb * nrb + rb (cb 0..3)
     auto out_tile = [&](const u32x4 (&af)[8], int t) {
         const int cb = t / nrb, rb = t - cb * nrb;
@@ -1918,7 +1756,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
         if (t + AL_NW < nt3) out_tile(afb, t + AL_NW);
     }
     __syncthreads();
-    AL_STAMP(4);
     // ---- phase 4: GraphNormalization over the RNA (functional.py:33-46), thread = (channel, row group of 8)
     {
         const int c = tid & 127, g = tid >> 7;
@@ -1949,7 +1786,6 @@ __global__ void __launch_bounds__(AL_NW * 64) k_attn_layer_rna(PackInfo pk, floa
         for (int q = 0; q < NRW; ++q) { const int row = g + 8 * q; if (row < n) xb[(size_t)row * RN_D + c] = fmaf(yv[q], a, bb); }
     }
     __syncthreads();
-    AL_STAMP(5);
 }
 
 // returns 0 when the fused per-RNA layer ran (head dim 16, 8 heads, every RNA of the batch <= AL_NR residues), 1 otherwise.
@@ -1961,15 +1797,6 @@ int launch_attn_layer_rna(const PackInfo& pk, float* x, const bf16_t* wqkv, cons
     static DevAttr attr;
     ensure_dyn_lds((const void*)k_attn_layer_rna, AL_LDS, attr);
     hipLaunchKernelGGL(k_attn_layer_rna, dim3(pk.B), dim3(AL_NW * 64), AL_LDS, s, pk, x, wqkv, bqkv, wout, bout, gscale, gshift, t_tot);
-#ifdef AL_STAMPS
-    {
-        unsigned long long hst[8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(al_dbg), sizeof(hst));
-        fprintf(stderr, "[attn layer stamps] cycles: x image %llu | qkv %llu | attention %llu | out-proj %llu | norm %llu | total %llu\n", hst[1] - hst[0],
-                hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4], hst[5] - hst[0]);
-    }
-#endif
     return 0;
 }
 

@@ -27,6 +27,13 @@
 #include <cstdlib>
 
 static_assert(RN_E_F16 == 1 && RN_P_F16 == 1, "k_resmpnn works on f16 e and f16 P / Q tables");
+// Timing ablations (RM_EXP_*: parts compiled out, WRONG results) and structural variants (RM_WAVES, RM_RING8, RM_EDB, RM_QROLL, RM_NO_EPI_FENCE) are
+// compile-time switches behind ONE build flag: tools/build_mpnn_variant.sh passes -DRN_EXPERIMENTS; build() never does.
+#if !defined(RN_EXPERIMENTS) && (defined(RM_EXP_NOQ) || defined(RM_EXP_NOESTORE) || defined(RM_EXP_NOELOAD) || defined(RM_EXP_NOMFMA) || defined(RM_EXP_NOGELU) || \
+                                 defined(RM_EXP_NOLDS) || defined(RM_EXP_STAGGER) || defined(RM_EXP_PRIO) || defined(RM_WAVES) || defined(RM_RING8) || defined(RM_EDB) || \
+                                 defined(RM_QROLL) || defined(RM_NO_EPI_FENCE))
+#error "experimental variants of k_resmpnn need -DRN_EXPERIMENTS (tools/build_mpnn_variant.sh)"
+#endif
 
 #ifndef RM_WAVES
 #define RM_WAVES 8                 // waves per workgroup (one workgroup per CU).  Measured at C2 (tools/ab_mpnn.sh, one box): 8 waves 155 - 158 us per

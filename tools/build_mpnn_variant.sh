@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/rna-mpnn_amd/csrc
 name=$1; shift
 mkdir -p $C/variants $ROOT/build/var
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value "$@" -c $C/kernels_mpnn.hip -o $ROOT/build/var/$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DRN_EXPERIMENTS "$@" -c $C/kernels_mpnn.hip -o $ROOT/build/var/$name.o
 objs=$(ls $ROOT/build/obj/*.o | grep -v kernels_mpnn.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/variants/$name.so $objs $ROOT/build/var/$name.o
 echo built $C/variants/$name.so
