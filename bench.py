@@ -276,7 +276,12 @@ def main():
         L = 10
         survey_bytes_nt = k * (2 * 128 * w + 2 * 4) + 4 * 128 * w
         kernel_bytes_nt = k * (2 * 128 * w + 4) + 4 * 128 * 2 + 2 * 128 * 4
-        first_bytes_nt = k * (128 * w + 4) + 2 * 128 * 2 + 2 * 128 * 4       # layer 1: message only - e read once, one P and one Q table
+        # layer 1: message only - one P and one Q table; e0 is WRITTEN once by the same launch when the edge embedding is fused into it (k > 16,
+        # default; + the residue's 256-byte geometry record), READ once in the two-launch form (RNAMPNN_EMBED_FUSED=0)
+        embed_fused = args.precision == "bf16" and k > 16 and os.environ.get("RNAMPNN_EMBED_FUSED") != "0" and os.environ.get("RNAMPNN_MPNN_V3") != "1"
+        first_bytes_nt = k * (128 * w + 4) + 2 * 128 * 2 + 2 * 128 * 4 + (256 if embed_fused else 0)
+        first_name = ("edge embedding + message launch of layer 1 (k_resmpnn<false, true, true>)" if embed_fused
+                      else "message-only launch of layer 1 (k_resmpnn<false, true>)")
         (ms_em, n_em), (ms_first, n_first) = prof_em, prof_first
         launch_ms = ms_em / max(n_em, 1)
         first_ms = ms_first / max(n_first, 1)
@@ -308,7 +313,7 @@ def main():
                 "nucleotides_per_launch": nt_call,
                 "mfma_issued_frac": issued_tf / peak_tf if issued_tf else None,
                 "mfma_useful_frac": issued_tf * min(k, 32) / 32 * 128 / mfma_per_block / peak_tf if issued_tf else None,
-                "first_launch": {"kernel": "message-only launch of layer 1 (k_resmpnn<false, true>)", "launch_ms": first_ms, "launches_timed": n_first,
+                "first_launch": {"kernel": first_name, "launch_ms": first_ms, "launches_timed": n_first,
                                  "algorithmic_bytes_per_nt": first_bytes_nt,
                                  "achieved": first_bytes_nt * nt_call / (first_ms * 1e-3) / 1e9 if n_first else None}}
         if measured_cfg and traffic_src:    # measured on exactly this configuration (profiles/)

@@ -619,6 +619,8 @@ static void node_pq(Run& r, const Mlp2& m, const float* h, bool edge) {
                         derp<float>(c, m.pq_b), 256, 0, nullptr, 0, edge ? r.w.pq_e : r.w.pq_m, 256, r.s);
 }
 
+static bool embed_fused_env() { const char* v = getenv("RNAMPNN_EMBED_FUSED"); return !(v && v[0] == '0'); }      // RNAMPNN_EMBED_FUSED=0: two launches (A/B; read per call)
+
 static MpnnW32 w32(rnampnn_ctx* c, const Mlp2& m) {
     MpnnW32 w;
     w.wc_t = derp<float>(c, m.wc_t);
@@ -635,12 +637,15 @@ static MpnnWB wbf(rnampnn_ctx* c, const Mlp2& m) {
 }
 
 // one fused step: [edge update with `we`] then [message + aggregation with `wm`]
-static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in, float* h_pre, float* msg_out) {
+static void mpnn_step(Run& r, const Mlp2* we, const Mlp2* wm, const float* h_in, float* h_pre, float* msg_out, bool embed_first = false) {
     rnampnn_ctx* c = r.c;
     int k = c->cfg.num_res_neighbours;
     bool timed = c->prof && c->ev_used + 2 <= c->ev.size() && (c->prof_seen++ % c->prof_stride) == 0;
     if (timed) { c->ev_kind[c->ev_used / 2] = (we && wm) ? 0 : 1; (void)hipEventRecord(c->ev[c->ev_used], r.s); }
-    if (r.fast) {
+    if (embed_first) {      // layer 1's message with the edge embedding computed in front of it (e0 written once, never re-read)
+        launch_resmpnn_embed_bf16(r.pk, k, r.w.nbr, (bf16_t*)r.w.e, r.w.geomh, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
+                                  derp<float>(c, c->edge_embed_b1p), r.w.p_m, r.w.q_m, wbf(c, *wm), h_pre, h_in, r.s);
+    } else if (r.fast) {
         launch_mpnn_bf16(r.pk, k, we != nullptr, wm != nullptr, r.w.nbr, (bf16_t*)r.w.e, r.w.p_e, r.w.q_e, r.w.p_m,
                          r.w.q_m, we ? wbf(c, *we) : MpnnWB{}, wm ? wbf(c, *wm) : MpnnWB{}, h_pre, msg_out, we && we->depth == 1,
                          wm ? h_in : nullptr, r.s);      // h_pre = h_in + mean of the messages (both paths)
@@ -680,8 +685,6 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
     carve(h, B, (size_t)nmax, (char*)ws, &r.w);
     r.pk.len = r.w.len; r.pk.cu = r.w.cu; r.pk.node_b = r.w.node_b;
     r.pk.B = B; r.pk.T = T; r.pk.Nmax = (int)nmax; r.pk.packed_in = cu_seqlens ? 1 : 0;
-    if (cu_seqlens) launch_lengths_from_cu(cu_seqlens, r.pk, r.s);
-    else launch_lengths(mask, r.pk, r.s);
     // the all-zero row Nmax of every gathered node table (phantom neighbour / invalid slot)
     size_t Nmax = r.pk.Nmax;
     ZeroRegions z{};
@@ -697,6 +700,9 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
         add(r.w.pq_e + Nmax * 256, 256 * sizeof(float));
         add(r.w.pq_m + Nmax * 256, 256 * sizeof(float));
     }
+    if (!cu_seqlens && launch_prepare_small(mask, r.pk, z, r.s)) return RNAMPNN_OK;
+    if (cu_seqlens) launch_lengths_from_cu(cu_seqlens, r.pk, r.s);
+    else launch_lengths(mask, r.pk, r.s);
     launch_zero_regions(z, r.s);
     return RNAMPNN_OK;
 }
@@ -762,7 +768,9 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
     if (rc) return rc;
     if (launch_knn(io->coords, r.pk, k, w.nbr, io->edge_index, s))
         return fail(RNAMPNN_ERR_UNSUPPORTED, "max_len %d too long for the LDS-resident k-NN row", io->T);
-    if (r.fast)
+    const bool embed_first = fused_first && L >= 1 && !io->e0 && resmpnn_covers(k, false, false) && embed_fused_env();
+    if (embed_first) { }
+    else if (r.fast)
         launch_edge_embed_bf16(r.pk, k, w.geomh, w.nbr, derp<bf16_t>(c, c->edge_embed_img), rawp(c, c->edge_embed[0].b),
                                derp<float>(c, c->edge_embed_b1p), (bf16_t*)w.e, s);
     else
@@ -778,7 +786,7 @@ static int forward_core(Run& r, rnampnn_handle h, const RnaMpnnForwardIO* io, co
     if (!fused_first) node_pq(r, c->mpnn[0].msg, w.hA, false);
     bool edge_pending = false;                                 // layer l-1's edge update not yet applied
     for (int l = 0; l < L; ++l) {
-        mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr);
+        mpnn_step(r, edge_pending ? &c->mpnn[l - 1].edge : nullptr, &c->mpnn[l].msg, w.hA, w.hB, nullptr, l == 0 && embed_first);
         bool tap_e = io->tap_layer == l + 1 && io->e_layer;
         edge_pending = l + 1 < L;                              // layer L's edge update is dead work
         const bool need_e = edge_pending || tap_e, need_m = l + 1 < L;

@@ -209,3 +209,20 @@ __host__ __device__ __forceinline__ int ch_efrag(int blk, int m) {
     int h = (m >> 2) & 1, i = (m & 3) + 4 * (m >> 3);
     return i < 8 ? 32 * blk + 8 * h + i : 32 * blk + 16 + 8 * h + (i - 8);
 }
+
+// Edge-embedding MLP image.  The 90 raw features are computed per lane half in a kernel-private
+// order (EMB_SLOTS slots per half, 7 k-steps of 16): slot p of half h sits at k = 16*(p>>3) + 8h + (p&7).
+#define EMB_KS 7
+#define EMB_SLOTS 56
+// Lane half h owns the NEIGHBOUR items 4h..4h+3 (atoms), 3h..3h+2 (unit bonds), 2h, 2h+1 (unit normals) - what its 28
+// floats of the half-split geometry record hold (kernels_f32.hip: geomh_record) - against ALL central items:
+//   p <  28: distance  central atom a = p >> 2   to neighbour atom   4h + (p & 3)        -> feature a*7 + b        (feature.py:414-418)
+//   p <  43: cosine    central bond a = (p-28)/3 to neighbour bond   3h + (p-28) % 3     -> feature 49 + a*5 + b   (feature.py:451-464)
+//   p <  51: cosine    central normal a = (p-43)>>1 to neighbour normal 2h + ((p-43)&1)  -> feature 74 + a*4 + b   (feature.py:493-512)
+// slots of items a half does not have (atom 7, bond 5) and p >= 51 carry zero weights.
+__host__ __device__ __forceinline__ int emb_feature_of_slot(int h, int p) {      // -> original feature id or -1
+    if (p < 28) { int a = p >> 2, b = 4 * h + (p & 3); return b <= 6 ? a * 7 + b : -1; }
+    if (p < 43) { int q = p - 28, a = q / 3, b = 3 * h + q % 3; return b <= 4 ? 49 + a * 5 + b : -1; }
+    if (p < 51) { int q = p - 43, a = q >> 1, b = 2 * h + (q & 1); return 74 + a * 4 + b; }
+    return -1;
+}

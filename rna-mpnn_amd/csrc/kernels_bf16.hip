@@ -88,22 +88,6 @@ void launch_build_mlp_image(const float* wc, int ld_wc, const float* w2, int ld_
     hipLaunchKernelGGL(k_build_mlp_image, dim3((total + 255) / 256), dim3(256), 0, s, wc, ld_wc, w2, ld_w2, b2, out_perm, img, b2p);
 }
 
-// Edge-embedding MLP image.  The 90 raw features are computed per lane half in a kernel-private
-// order (EMB_SLOTS slots per half, 7 k-steps of 16): slot p of half h sits at k = 16*(p>>3) + 8h + (p&7).
-#define EMB_KS 7
-#define EMB_SLOTS 56
-// Lane half h owns the NEIGHBOUR items 4h..4h+3 (atoms), 3h..3h+2 (unit bonds), 2h, 2h+1 (unit normals) - what its 28
-// floats of the half-split geometry record hold (kernels_f32.hip: geomh_record) - against ALL central items:
-//   p <  28: distance  central atom a = p >> 2   to neighbour atom   4h + (p & 3)        -> feature a*7 + b        (feature.py:414-418)
-//   p <  43: cosine    central bond a = (p-28)/3 to neighbour bond   3h + (p-28) % 3     -> feature 49 + a*5 + b   (feature.py:451-464)
-//   p <  51: cosine    central normal a = (p-43)>>1 to neighbour normal 2h + ((p-43)&1)  -> feature 74 + a*4 + b   (feature.py:493-512)
-// slots of items a half does not have (atom 7, bond 5) and p >= 51 carry zero weights.
-__host__ __device__ __forceinline__ int emb_feature_of_slot(int h, int p) {      // -> original feature id or -1
-    if (p < 28) { int a = p >> 2, b = 4 * h + (p & 3); return b <= 6 ? a * 7 + b : -1; }
-    if (p < 43) { int q = p - 28, a = q / 3, b = 3 * h + q % 3; return b <= 4 ? 49 + a * 5 + b : -1; }
-    if (p < 51) { int q = p - 43, a = q >> 1, b = 2 * h + (q & 1); return 74 + a * 4 + b; }
-    return -1;
-}
 __global__ void k_build_embed_image(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ b1,
                                     bf16_t* __restrict__ img, float* __restrict__ b1p) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -991,6 +975,10 @@ struct ChainW {
 // chunk, so "chunk c has landed" is the counted wait vmcnt(8 * chunks issued after c) followed by a
 // raw s_barrier (a __syncthreads() would drain the ring: cdna guide, "Pipelining across barriers").
 #define CH_RING 4
+// timing ablations of k_ffn_chain (WRONG results; tools/build_mpnn_variant.sh with RN_VARIANT_SRC=kernels_bf16.hip passes -DRN_EXPERIMENTS)
+#if !defined(RN_EXPERIMENTS) && (defined(CH_EXP_NODMA) || defined(CH_EXP_NOGELU) || defined(CH_EXP_NOLDS) || defined(CH_EXP_NOBAR))
+#error "k_ffn_chain ablations need -DRN_EXPERIMENTS"
+#endif
 #ifndef CH_GELU
 #define CH_GELU 1
 #endif
@@ -1005,6 +993,9 @@ __device__ __forceinline__ void chain_issue(const u32x4* __restrict__ img, u32x4
 // one of the 8 DMA pieces of chunk c (issued between the MFMAs of the chunk that runs three chunks earlier: the ~100
 // cycles a DMA holds the wave's issue then pass under a busy matrix pipe instead of in front of it)
 __device__ __forceinline__ void chain_issue_piece(const u32x4* __restrict__ img, u32x4* ring, int c, int tid, int i) {
+#ifdef CH_EXP_NODMA
+    return;
+#endif
     const u32x4* src = img + (size_t)c * 2048 + tid + i * 256;
     u32x4* dst = ring + (c % CH_RING) * 2048 + (tid & ~63) + i * 256;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -1014,7 +1005,9 @@ __device__ __forceinline__ void chain_wait(int chunks_after) {       // folded t
     if (chunks_after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (chunks_after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef CH_EXP_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
 }
 
 // one Linear of the chain = NOB output blocks of NKS k-steps = NOB*NKS/32 chunks, starting at global
@@ -1032,6 +1025,9 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
     // quarter t of block ob's epilogue: GELU + repack into out[] (hidden layers) or the f32 store of 4 channels (last layer)
     auto granule = [&](const f32x16& acc, auto obc, auto tc) {
         constexpr int ob = decltype(obc)::value, t = decltype(tc)::value;
+#ifdef CH_EXP_NOGELU
+        if constexpr (!LAST) { out[2 * ob][t] = __float_as_uint(acc[2 * t]); out[2 * ob + 1][t] = __float_as_uint(acc[8 + 2 * t]); return; }
+#endif
         if constexpr (!LAST) {
 #if CH_GELU == 2           /* experiment: f32 sigmoid-form GELU (2.7e-4) */
             const f16x4 g = cvt_h4(gelu_fast(acc[2 * t]), gelu_fast(acc[2 * t + 1]), gelu_fast(acc[8 + 2 * t]), gelu_fast(acc[8 + 2 * t + 1]));
@@ -1066,7 +1062,9 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
             static_for<NKS>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value, m = o * NKS + ks;      // m: MFMA number within the chunk (32 per chunk)
                 acc = mfma32h(fr[m & 7], in[ks], acc);    // f16 operands in every layer
+#ifndef CH_EXP_NOLDS
                 if constexpr (m + 8 < 32) fr[m & 7] = buf[(m + 8) * 64];
+#endif
                 if constexpr (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ob > 0) {                        // granules of the previous block behind this block's MFMAs
@@ -1403,6 +1401,165 @@ __global__ void __launch_bounds__(256, 2) k_node_update(PackInfo pk, const float
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the same update with the GraphNormalization statistics computed IN the kernel: one workgroup per RNA (n <= 32 NW rows), every row of the RNA
+// in the registers of its lanes.  Per-channel sums over the rows: DPP tree over the 32 lanes of a half-wave (fixed order), the waves' partials
+// combined through LDS by 128 threads in wave order - two passes (mean, then squared deviations: functional.py:33-38 and the note in k_gn_coef).
+// Replaces the k_gn_coef launch in front of k_node_update (8 us of a 2.2 ms C2 forward, ten times) when the batch's padded length allows it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {      // (bound_ctrl with the full row mask: lets the compiler fold the move into v_add_f32_dpp)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf));
+}
+// Sums over the 32 lanes of a half-wave, two values at a time: v_permlane16_swap_b32 exchanges the odd 16-lane rows of `a` with the even rows of
+// `b`, so a' + b' holds a[r] + a[r + 16] on the even rows and b[r] + b[r + 16] on the odd rows - half the values, each on half the lanes; four
+// butterfly steps inside the rows finish both.  Result: the total of `a` on lanes 0..15 of the half-wave, of `b` on lanes 16..31 (fixed order).
+__device__ __forceinline__ float half_wave_sum2(float a, float b) {
+    // (inline asm: this compiler folds the builtin's two results into one register - tools/ubench/permlane_probe.hip; the s_nops are the
+    //  VALU-write -> permlane-read and permlane-write -> DPP-read wait states the compiler would have inserted)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float v = a + b;
+    v += dpp_f32<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_f32<0x140, 0xf>(v);       // row_mirror
+    return v;
+}
+template <int NJOBS, int NW>
+__global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+        const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ h_out, PqJob j0, PqJob j1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* img = reinterpret_cast<u32x4*>(smem);
+    float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);      // [2][128]
+    float* lds_part = lds_bias + 256;                                       // [NW][128] per-wave partial sums
+    float* lds_mean = lds_part + NW * 128;                                  // [128]
+    float* lds_ab = lds_mean + 128;                                         // [128] a | [128] b
+    const int b = blockIdx.x;
+    const int n = pk.len[b];
+    if (n <= 0) return;
+    const int base = pk.cu[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int lrow = 32 * wave + r;
+    const bool ok = lrow < n;
+    const int row = base + (ok ? lrow : 0);
+    f32x4 vx[8][2], va[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c0 = 16 * s + 8 * h;
+        vx[s][0] = *reinterpret_cast<const f32x4*>(x + (size_t)row * RN_D + c0);
+        vx[s][1] = *reinterpret_cast<const f32x4*>(x + (size_t)row * RN_D + c0 + 4);
+        if (add) {
+            va[s][0] = *reinterpret_cast<const f32x4*>(add + (size_t)row * RN_D + c0);
+            va[s][1] = *reinterpret_cast<const f32x4*>(add + (size_t)row * RN_D + c0 + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_image_dma<NW * 64>(img, reinterpret_cast<const u32x4*>(j0.img), tid);
+    if (NJOBS > 1) stage_image_dma<NW * 64>(img + 4096, reinterpret_cast<const u32x4*>(j1.img), tid);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < 128) lds_bias[tid] = j0.bias[tid];
+    else if (NJOBS > 1 && tid < 256) lds_bias[tid] = j1.bias[tid - 128];
+    float sc_c = 0.f, sh_c = 0.f;
+    if (tid < 128) { sc_c = scale[tid]; sh_c = shift[tid]; }
+    if (add) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { vx[s][0] += va[s][0]; vx[s][1] += va[s][1]; }
+    }
+    const int nwb = (n + 31) >> 5;                         // waves that hold rows
+    auto reduce_rows = [&](auto&& value) {                 // value(s, p, i) of this lane -> lds_part[wave][channel]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                      // lane r = 0 of a half ends with channel block s, lane r = 16 with block s + 4
+            f32x4 t0, t1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { t0[i] = half_wave_sum2(value(s, 0, i), value(s + 4, 0, i)); t1[i] = half_wave_sum2(value(s, 1, i), value(s + 4, 1, i)); }
+            if ((r & 15) == 0) {
+                const int sb = s + (r >> 4) * 4;
+                *reinterpret_cast<f32x4*>(lds_part + wave * 128 + 16 * sb + 8 * h) = t0;
+                *reinterpret_cast<f32x4*>(lds_part + wave * 128 + 16 * sb + 8 * h + 4) = t1;
+            }
+        }
+    };
+    auto combine = [&]() -> float {                        // thread c < 128: the waves' partials of channel c, in wave order
+        float t = lds_part[tid];
+        for (int w = 1; w < nwb; ++w) t += lds_part[w * 128 + tid];
+        return t;
+    };
+    const float fn = (float)n;
+    // pass 1: mean
+    reduce_rows([&](int s, int p, int i) { return ok ? vx[s][p][i] : 0.f; });
+    __syncthreads();
+    float mean_c = 0.f;
+    if (tid < 128) { mean_c = combine() / fn; lds_mean[tid] = mean_c; }
+    __syncthreads();
+    f32x4 mu[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        mu[s][0] = *reinterpret_cast<const f32x4*>(lds_mean + 16 * s + 8 * h);
+        mu[s][1] = *reinterpret_cast<const f32x4*>(lds_mean + 16 * s + 8 * h + 4);
+    }
+    // pass 2: squared deviations of the valid rows; the T - n padded rows enter as (0 - mean)^2
+    reduce_rows([&](int s, int p, int i) { const float d = vx[s][p][i] - mu[s][p][i]; return ok ? d * d : 0.f; });
+    __syncthreads();
+    if (tid < 128) {
+        const float sq = combine(), pad = (float)(t_tot - n);
+        const float var = (sq + pad * mean_c * mean_c) / fn;
+        const float a = sc_c / sqrtf(var + kSEPS);
+        lds_ab[tid] = a;
+        lds_ab[128 + tid] = sh_c - mean_c * a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int c0 = 16 * s + 8 * h;
+        const f32x4 ca0 = *reinterpret_cast<const f32x4*>(lds_ab + c0), ca1 = *reinterpret_cast<const f32x4*>(lds_ab + c0 + 4);
+        const f32x4 cb0 = *reinterpret_cast<const f32x4*>(lds_ab + 128 + c0), cb1 = *reinterpret_cast<const f32x4*>(lds_ab + 128 + c0 + 4);
+        vx[s][0] = vx[s][0] * ca0 + cb0; vx[s][1] = vx[s][1] * ca1 + cb1;
+    }
+    u32x4 xf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const f32x4 v0 = vx[s][0], v1 = vx[s][1];
+        xf[s] = u32x4{p_pack2(v0[0], v0[1]), p_pack2(v0[2], v0[3]), p_pack2(v1[0], v1[1]), p_pack2(v1[2], v1[3])};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_landed();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ok && h_out) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int c0 = 16 * s + 8 * h;
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0) = vx[s][0];
+            *reinterpret_cast<f32x4*>(h_out + (size_t)row * RN_D + c0 + 4) = vx[s][1];
+        }
+    }
+    __syncthreads();
+    if (wave >= nwb) return;                                // (no barrier below)
+#pragma unroll
+    for (int jb = 0; jb < NJOBS; ++jb) {
+        const PqJob& jbq = jb == 0 ? j0 : j1;
+        const u32x4* im = img + jb * 4096;
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+            f32x16 acc;
+            if (ob < 4) acc = init_vec16(lds_bias + jb * 128 + 32 * ob + 16 * h);
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mfma32h(im[(ob * 8 + ks) * 64 + lane], xf[ks], acc);
+            if (ok) {
+                bf16_t* row_p = (ob < 4 ? jbq.p : jbq.q) + (size_t)row * RN_D + 32 * (ob & 3);
+                const bool efr = ob < 4 && jbq.p_efrag;
+                u32x4* d0 = reinterpret_cast<u32x4*>(row_p + (efr ? 8 * h : 16 * h));
+                u32x4* d1 = reinterpret_cast<u32x4*>(row_p + (efr ? 16 + 8 * h : 16 * h + 8));
+                *d0 = u32x4{p_pack2(acc[0], acc[1]), p_pack2(acc[2], acc[3]), p_pack2(acc[4], acc[5]), p_pack2(acc[6], acc[7])};
+                *d1 = u32x4{p_pack2(acc[8], acc[9]), p_pack2(acc[10], acc[11]), p_pack2(acc[12], acc[13]), p_pack2(acc[14], acc[15])};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // [P | Q] image of one MLP's first Linear w0 [128][384]: ob < 4 rows ch_nat(ob) of w0[:, 0:128], ob >= 4 of w0[:, 128:256].
 // efrag = 1 (depth-1 edge MLP, EDGE1 of the fused kernel): the P rows - hence the P words k_node_update writes - follow ch_efrag,
 // the order of that kernel's one accumulator tile; b1p = the bias in the matching order (b1p[32 ob + 16 h + i] <-> accumulator
@@ -1426,6 +1583,22 @@ void launch_build_pq_image(const float* w0, const float* b1, int efrag, bf16_t* 
 void launch_node_update(const PackInfo& pk, const float* x, const float* add, const float* scale, const float* shift, int t_tot,
                         float* coef, float* h_out, int njobs, const NodeJob& job0, const NodeJob& job1, hipStream_t s) {
     const PqJob j0 = job0, j1 = njobs > 1 ? job1 : NodeJob{};
+    // Every RNA of the batch fits the rows of one workgroup (padded length <= 256) and is long enough for a workgroup of its own: the statistics
+    // are computed inside the update kernel (RNAMPNN_NODE_UPDATE_RNA=0: the two-launch form; read per call)
+    static const auto rna_form_env = []() { const char* v = getenv("RNAMPNN_NODE_UPDATE_RNA"); return !(v && v[0] == '0'); };
+    if (scale && pk.T >= 48 && pk.T <= 256 && rna_form_env()) {
+#define NU_RNA(J, W)                                                                                                            \
+        do {                                                                                                                    \
+            static DevAttr attr;                                                                                                \
+            constexpr size_t lds = (size_t)(J) * 65536 + 1024 + (W) * 512 + 3 * 512;                                            \
+            ensure_dyn_lds((const void*)k_node_update_rna<J, W>, lds, attr);                                                    \
+            hipLaunchKernelGGL((k_node_update_rna<J, W>), dim3(pk.B), dim3((W) * 64), lds, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1); \
+        } while (0)
+        if (njobs == 1) { if (pk.T <= 128) NU_RNA(1, 4); else NU_RNA(1, 8); }
+        else { if (pk.T <= 128) NU_RNA(2, 4); else NU_RNA(2, 8); }
+#undef NU_RNA
+        return;
+    }
     if (scale) hipLaunchKernelGGL(k_gn_coef, dim3(pk.B, 4), dim3(256), 0, s, pk, x, add, scale, shift, t_tot, coef);
     dim3 grid((pk.Nmax + 127) / 128);
     // Measured and NOT kept (round 3, C2, 21.9 us per launch for this form): (a) four workgroups per 128-row block (one per job and P / Q half,

@@ -48,7 +48,8 @@ static_assert(RN_E_F16 == 1 && RN_P_F16 == 1, "k_resmpnn works on f16 e and f16 
 #define RM_LDS_Z (RM_LDS_GB + 512 + 128)             // 512 zero bytes: accumulator init of absent edges (= 128 mod 256: banks 32.. of the
                                                      // row, which no P / bias read of the same instruction touches)
 #define RM_LDS_CTR (RM_LDS_Z + 512)                  // block-dealing counter of the workgroup
-#define RM_LDS_BYTES (RM_LDS_CTR + 16)
+#define RM_LDS_B0 (RM_LDS_CTR + 16)                  // EMBED: bias of the edge embedding's first Linear (a b0), natural channel order
+#define RM_LDS_BYTES (RM_LDS_B0 + 512)
 static_assert(RM_LDS_Z % 256 == 128 && RM_LDS_BYTES <= 160 * 1024, "LDS layout");
 
 __device__ __forceinline__ u32x4* rm_efrag(bf16_t* e, int blk, int lane) { return reinterpret_cast<u32x4*>(e) + (size_t)blk * 512 + lane; }
@@ -76,11 +77,13 @@ __device__ __forceinline__ f16x4 rm_h4(unsigned w0, unsigned w1) {
 #ifdef RM_EXP_NOGELU
 #define phi4s(y) (y)
 #endif
-template <bool DO_EDGE, bool DO_MSG>
+template <bool DO_EDGE, bool DO_MSG, bool EMBED = false>
 __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInfo pk, int k, const int* __restrict__ nbr, bf16_t* __restrict__ e,
         const bf16_t* __restrict__ p_e, const bf16_t* __restrict__ q_e, const bf16_t* __restrict__ p_m, const bf16_t* __restrict__ q_m,
         const float* __restrict__ h_res, const bf16_t* __restrict__ img_e_g, const float* __restrict__ b2e,
-        const bf16_t* __restrict__ img_m_g, const float* __restrict__ b2m, float* __restrict__ agg) {
+        const bf16_t* __restrict__ img_m_g, const float* __restrict__ b2m, float* __restrict__ agg,
+        const float* __restrict__ geomh = nullptr, const float* __restrict__ ee_b0 = nullptr) {
+    static_assert(!EMBED || (!DO_EDGE && DO_MSG), "EMBED: the edge embedding (feature.py:386-571) in front of the message of layer 1");
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     u32x4* img_e = reinterpret_cast<u32x4*>(smem);
     u32x4* img_m = img_e + 4096;
@@ -127,15 +130,19 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
         const int b0 = blk < blk_end ? blk : 0;
         const int i0 = b0 * k + r;
         jraw = nbr[i0 > last_idx ? last_idx : i0];
+        if (!EMBED) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ef[s] = rm_efrag(e, b0, lane)[64 * s];
+            for (int s = 0; s < 8; ++s) ef[s] = rm_efrag(e, b0, lane)[64 * s];
+        }
         if (DO_EDGE) pn_e = reinterpret_cast<const unsigned*>(p_e + (size_t)b0 * RN_D)[lane];
         if (DO_MSG) pn_m = reinterpret_cast<const unsigned*>(p_m + (size_t)b0 * RN_D)[lane];
     }
     if (DO_EDGE) stage_image_dma<NW * 64>(img_e, reinterpret_cast<const u32x4*>(img_e_g), tid);
+    if (EMBED) stage_image_dma<NW * 64, (4 * EMB_KS + 32) * 64>(img_e, reinterpret_cast<const u32x4*>(img_e_g), tid);      // [4 mb][7 s] first Linear | [4 ob][8 ks] second
     if (DO_MSG) stage_image_dma<NW * 64>(img_m, reinterpret_cast<const u32x4*>(img_m_g), tid);
+    if (EMBED && tid >= 256 + 64 && tid < 256 + 64 + 128) reinterpret_cast<float*>(smem + RM_LDS_B0)[tid - 320] = kGA * ee_b0[tid - 320];
     if (tid < 128) {
-        reinterpret_cast<float*>(smem + RM_LDS_BE)[tid] = DO_EDGE ? b2e[tid] : 0.f;
+        reinterpret_cast<float*>(smem + RM_LDS_BE)[tid] = (DO_EDGE || EMBED) ? b2e[tid] : 0.f;       // (EMBED: the embedding's second bias, e-fragment row order)
         const float bm = DO_MSG ? b2m[tid] : 0.f;            // (a b2: the images' biases are stored in the scaled activation domain)
         const f16x2 bh = cvt_h2(bm, bm);
         reinterpret_cast<unsigned*>(smem + RM_LDS_BM)[tid] = __builtin_bit_cast(unsigned, bh);
@@ -298,8 +305,16 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
         RM_EFENCE();
     };
 
+    // EMBED: the neighbour's half-split geometry record (28 floats of the items this lane half owns; kernels_f32.hip: geomh_record)
+    f32x4 nrec[7];
+    auto load_rec = [&](int jj) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(geomh + (size_t)(jj >= 0 ? jj : 0) * RN_GEOMH + 32 * h);
+#pragma unroll
+        for (int v = 0; v < 7; ++v) nrec[v] = src[v];
+    };
     // ---- prologue: state of the first block, fragments and accumulator init of its first chain
     int j = (slot_ok && blk < ntot) ? jraw : -1;
+    if constexpr (EMBED) load_rec(j);
     gather_q(std::integral_constant<int, 0>{}, DO_EDGE ? q_e : q_m, j);
     gather_q(std::integral_constant<int, 1>{}, DO_EDGE ? q_e : q_m, j);
 #ifdef RM_QFULL
@@ -309,7 +324,7 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
     stage_p();
 #pragma unroll
     for (int s = 0; s < RM_RING; ++s) wf[s] = RM_FRAG(C_FIRST, s);
-    T = rm_ld16(smem, j >= 0 ? (DO_EDGE ? off_pe : off_pm) : (unsigned)RM_LDS_Z);
+    if constexpr (!EMBED) T = rm_ld16(smem, j >= 0 ? (DO_EDGE ? off_pe : off_pm) : (unsigned)RM_LDS_Z);
     RM_FENCE();
 
 #ifdef RM_EXP_STAGGER      /* experiment: delay the second-dispatched half of the workgroup (waves that share SIMDs with the first half) */
@@ -367,6 +382,83 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
                 for (int s = 0; s < 8; ++s) ef[s] = rm_efrag(e, nb_c, lane)[64 * s];
             }
         }
+        if constexpr (EMBED) {
+            // ---- edge featurisation + embedding MLP of THIS block (feature.py:386-571; the arithmetic of k_edge_embed_bf16): e0 is formed in the
+            // registers the message MLP reads it from and stored once - the 236 MB re-read of e0 and one launch disappear.  The CENTRAL residue
+            // is wave-uniform: its record is read with scalar loads and enters the vector arithmetic as SGPR operands.
+            const float* __restrict__ gc = geomh + (size_t)__builtin_amdgcn_readfirstlane(blk) * RN_GEOMH;
+            auto catom = [&](int a, int d) { return a < 4 ? gc[3 * a + d] : gc[32 + 3 * (a - 4) + d]; };
+            auto cbond = [&](int a, int d) { return a < 3 ? gc[12 + 3 * a + d] : gc[32 + 12 + 3 * (a - 3) + d]; };
+            auto cnorm = [&](int a, int d) { return a < 2 ? gc[21 + 3 * a + d] : gc[32 + 21 + 3 * (a - 2) + d]; };
+            float nl[28];
+#pragma unroll
+            for (int v = 0; v < 7; ++v) { nl[4 * v] = nrec[v][0]; nl[4 * v + 1] = nrec[v][1]; nl[4 * v + 2] = nrec[v][2]; nl[4 * v + 3] = nrec[v][3]; }
+            float ft[EMB_SLOTS];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {                          // 28 distances
+                const float ax = catom(a, 0), ay = catom(a, 1), az = catom(a, 2);
+#pragma unroll
+                for (int bl = 0; bl < 4; ++bl) {
+                    const float dx = nl[3 * bl] - ax, dy = nl[3 * bl + 1] - ay, dz = nl[3 * bl + 2] - az;
+                    ft[4 * a + bl] = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, kSEPS))));
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {                          // 15 bond cosines
+                const float ax = cbond(a, 0), ay = cbond(a, 1), az = cbond(a, 2);
+#pragma unroll
+                for (int bl = 0; bl < 3; ++bl) ft[28 + 3 * a + bl] = fmaf(az, nl[12 + 3 * bl + 2], fmaf(ay, nl[12 + 3 * bl + 1], ax * nl[12 + 3 * bl]));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {                          // 8 normal cosines
+                const float ax = cnorm(a, 0), ay = cnorm(a, 1), az = cnorm(a, 2);
+#pragma unroll
+                for (int bl = 0; bl < 2; ++bl) ft[43 + 2 * a + bl] = fmaf(az, nl[21 + 3 * bl + 2], fmaf(ay, nl[21 + 3 * bl + 1], ax * nl[21 + 3 * bl]));
+            }
+#pragma unroll
+            for (int pz = 51; pz < EMB_SLOTS; ++pz) ft[pz] = 0.f;
+            u32x4 xf[EMB_KS];
+#pragma unroll
+            for (int s7 = 0; s7 < EMB_KS; ++s7)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xf[s7][t] = p_pack2(ft[8 * s7 + 2 * t], ft[8 * s7 + 2 * t + 1]);
+            RM_FENCE();
+            const unsigned emask = valid ? 0xffffffffu : 0u;
+            static_for<4>([&](auto mbc) {                      // Linear(90, 128): T = a b0 + a W0 . features
+                constexpr int mb = decltype(mbc)::value;
+                T = rm_ld16(smem, RM_LDS_B0 + 128 * mb + 64 * h);
+#pragma unroll
+                for (int s7 = 0; s7 < EMB_KS; ++s7) T = mfma32h(img_e[(mb * EMB_KS + s7) * 64 + lane], xf[s7], T);
+                asm volatile("" : "+v"(T) :: "memory");
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f16x4 x = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
+                    const f16x4 g = x * phi4s(x);
+                    hb[2 * mb + (v >> 1)][2 * (v & 1)] = __builtin_bit_cast(unsigned, lo2(g));
+                    hb[2 * mb + (v >> 1)][2 * (v & 1) + 1] = __builtin_bit_cast(unsigned, hi2(g));
+                }
+                RM_FENCE();
+            });
+            static_for<4>([&](auto obc) {                      // Linear(128, 128) -> GELU -> e0 (rows in e-fragment order); absent edges and padding slots: zeros
+                constexpr int ob = decltype(obc)::value;
+                T = rm_ld16(smem, RM_LDS_BE + 128 * ob + 64 * h);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) T = mfma32h(img_e[(4 * EMB_KS + ob * 8 + ks) * 64 + lane], hb[ks], T);
+                asm volatile("" : "+v"(T) :: "memory");
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f16x4 x = cvt_h4(T[4 * v], T[4 * v + 1], T[4 * v + 2], T[4 * v + 3]);
+                    const f16x4 g = x * phi4s(x);
+                    const int sp = v >> 1, t = 2 * (v & 1);
+                    ef[2 * ob + sp][t] = __builtin_bit_cast(unsigned, lo2(g)) & emask;
+                    ef[2 * ob + sp][t + 1] = __builtin_bit_cast(unsigned, hi2(g)) & emask;
+                    if (v & 1) rm_efrag(e, blk, lane)[64 * (2 * ob + sp)] = ef[2 * ob + sp];
+                }
+                RM_FENCE();
+            });
+            T = rm_ld16(smem, (unsigned)a_pm);                 // accumulator init of the message MLP's first chain
+            RM_FENCE();
+        }
         if constexpr (DO_MSG) {
             // message Linear 1 on the updated e
             chain(std::integral_constant<int, 8>{}, no_extra); RM_GQ_ROLL(I2{}, q_m, j); epi_first(I0{}, a_pm + 128);
@@ -375,11 +467,12 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
             // (k-step s of the last chain is the last reader of ef[s]: the next block's fragment is requested behind it)
             chain(std::integral_constant<int, 11>{}, [&](auto sc) {
 #if !defined(RM_EXP_NOELOAD) && !defined(RM_EDB)
-                constexpr int s = decltype(sc)::value; ef[s] = rm_efrag(e, nb_c, lane)[64 * s];
+                if constexpr (!EMBED) { constexpr int s = decltype(sc)::value; ef[s] = rm_efrag(e, nb_c, lane)[64 * s]; }
 #endif
             });
             epi_first(I3{}, -1);
             stage_p();                                     // the next block's P rows (this block's accumulator inits have all been read)
+            if constexpr (EMBED) load_rec(jn);             // ... and its neighbour records
             float hres[4] = {0.f, 0.f, 0.f, 0.f};
             if (h_res) {
 #pragma unroll
@@ -389,7 +482,7 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
             chain(std::integral_constant<int, 12>{}, no_extra); RM_GQ_FULL(DO_EDGE ? q_e : q_m, jn); epi_mean(I0{}, -1, blk, cabs, inv, hres[0]);
             chain(std::integral_constant<int, 13>{}, no_extra); epi_mean(I1{}, -1, blk, cabs, inv, hres[1]);
             chain(std::integral_constant<int, 14>{}, no_extra); RM_GQ_ROLL(I0{}, DO_EDGE ? q_e : q_m, jn); epi_mean(I2{}, -1, blk, cabs, inv, hres[2]);
-            chain(std::integral_constant<int, 15>{}, no_extra); RM_GQ_ROLL(I1{}, DO_EDGE ? q_e : q_m, jn); epi_mean(I3{}, a_next, blk, cabs, inv, hres[3]);
+            chain(std::integral_constant<int, 15>{}, no_extra); RM_GQ_ROLL(I1{}, DO_EDGE ? q_e : q_m, jn); epi_mean(I3{}, EMBED ? -1 : a_next, blk, cabs, inv, hres[3]);
         }
 #ifdef RM_EDB
 #pragma unroll
@@ -408,6 +501,10 @@ __global__ void __launch_bounds__(RM_WAVES * 64, RM_WAVES / 4) k_resmpnn(PackInf
     for (int s = 0; s < 4; ++s) { asm volatile("" :: "v"(q[s])); asm volatile("" :: "v"(wf[s])); }
     if (RM_RING == 8) { for (int s = 4; s < 8; ++s) asm volatile("" :: "v"(wf[s])); }
     asm volatile("" :: "v"(T));
+    if constexpr (EMBED) {
+#pragma unroll
+        for (int v = 0; v < 7; ++v) asm volatile("" :: "v"(nrec[v]));
+    }
 #undef RM_GQ_ROLL
 #undef RM_GQ_FULL
 #undef RM_EFENCE
@@ -438,4 +535,18 @@ void launch_resmpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, c
     else if (do_edge) RM_LAUNCH(true, false);
     else RM_LAUNCH(false, true);
 #undef RM_LAUNCH
+}
+
+// Layer 1's message launch with the edge embedding in front of it: e0 is computed from the geometry records, stored once and consumed from registers.
+void launch_resmpnn_embed_bf16(const PackInfo& pk, int k, const int* nbr, bf16_t* e, const float* geomh, const bf16_t* ee_img, const float* ee_b0,
+                               const float* ee_b1p, const bf16_t* p_m, const bf16_t* q_m, MpnnWB wm, float* agg, const float* h_res, hipStream_t s) {
+    int grid = (pk.Nmax + RM_WAVES - 1) / RM_WAVES;
+    if (grid >= 8) grid = (grid + 7) & ~7;
+    const int cus = rn_num_cus();
+    if (grid > cus) grid = cus;
+    if (grid < 1) grid = 1;
+    static DevAttr attr;
+    ensure_dyn_lds((const void*)k_resmpnn<false, true, true>, RM_LDS_BYTES, attr);
+    hipLaunchKernelGGL((k_resmpnn<false, true, true>), dim3(grid), dim3(RM_WAVES * 64), RM_LDS_BYTES, s, pk, k, nbr, e, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, p_m, q_m, h_res, ee_img, ee_b1p, wm.img, wm.b2p, agg, geomh, ee_b0);
 }

@@ -118,3 +118,51 @@ def test_two_ranks_on_one_gpu_overlap_equals_flat_allreduce():
            "--master-port", "29543", os.path.join(REPO, "tests", "_ddp_overlap_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DDP_OVERLAP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_embed_fused_first_launch_is_bit_identical_to_the_two_launch_form(monkeypatch):
+    """at k > 16 the edge embedding (feature.py:386-571) runs inside layer 1's message launch (k_resmpnn<false, true, true>:
+    e0 goes from the embedding's accumulators to the message MLP's operand registers and is stored once); RNAMPNN_EMBED_FUSED=0 runs
+    k_edge_embed_bf16 + the plain message launch.  Same arithmetic in the same order: logits, the layer-1 node tap and the layer-1 edge tap
+    (which re-reads the stored e0) are equal bit for bit on a ragged batch with a 1-residue and a 64-residue (= padding_len) RNA."""
+    from rnampnn.utils import synth
+    model = _small("bf16", num_res_mpnn_layers=4).eval()
+    coords, mask, _ = synth.synth_batch([64, 20, 47, 33, 5, 58, 31, 1], first_index=77)
+    c, m = torch.from_numpy(coords), torch.from_numpy(mask)
+    model.profile_enable(True)
+    fused = model(c, m).clone()
+    n_fused = model.profile_read()[1]
+    taps_f = {k: v.clone() for k, v in model.forward_taps(c, m, ["h_layer", "e_layer"], tap_layer=1).items() if torch.is_tensor(v)}
+    monkeypatch.setenv("RNAMPNN_EMBED_FUSED", "0")
+    two = model(c, m).clone()
+    taps_t = {k: v.clone() for k, v in model.forward_taps(c, m, ["h_layer", "e_layer"], tap_layer=1).items() if torch.is_tensor(v)}
+    monkeypatch.delenv("RNAMPNN_EMBED_FUSED")
+    model.profile_enable(False)
+    assert n_fused == 4                                     # (one timed fused-step launch per layer either way)
+    assert torch.isfinite(fused).all() and torch.equal(fused, two)
+    assert set(taps_f) == set(taps_t) and {"h_layer", "e_layer"} <= set(taps_f)
+    for name in taps_f:
+        assert torch.equal(taps_f[name], taps_t[name]), name
+
+
+def test_node_update_with_in_kernel_graphnorm_statistics_matches_the_two_launch_form(monkeypatch):
+    """Between two ResMPNN steps the residual + GraphNormalization (functional.py:33-46) + [P | Q] projections run as ONE kernel per RNA
+    when the padded length is 48..256 (k_node_update_rna: the per-RNA statistics from a fixed-order lane tree, two passes);
+    RNAMPNN_NODE_UPDATE_RNA=0 runs k_gn_coef + k_node_update.  Same arithmetic up to the f32 summation order of the statistics:
+    layer taps and logits agree to 1e-4 of their scale; padded lengths 64 (4 waves per RNA) and 150 (8 waves), RNAs of 1 and T residues."""
+    from rnampnn.utils import synth
+    for T, lens in ((64, [64, 20, 47, 33, 5, 58, 31, 1]), (150, [150, 97, 1, 129, 33, 140])):
+        model = _small("bf16", num_res_mpnn_layers=3, padding_len=T).eval()
+        coords, mask, _ = synth.synth_batch(lens, first_index=11)
+        c, m = torch.from_numpy(coords), torch.from_numpy(mask)
+        new = model(c, m).clone()
+        taps_n = {k: v.clone() for k, v in model.forward_taps(c, m, ["h_layer", "e_layer"], tap_layer=2).items() if torch.is_tensor(v)}
+        monkeypatch.setenv("RNAMPNN_NODE_UPDATE_RNA", "0")
+        old = model(c, m).clone()
+        taps_o = {k: v.clone() for k, v in model.forward_taps(c, m, ["h_layer", "e_layer"], tap_layer=2).items() if torch.is_tensor(v)}
+        monkeypatch.delenv("RNAMPNN_NODE_UPDATE_RNA")
+        assert torch.isfinite(new).all() and (new[mask == 0] == 0).all()
+        assert not torch.equal(new, old)                          # (a different kernel really ran)
+        for a, b in [(new, old)] + [(taps_n[k], taps_o[k]) for k in ("h_layer", "e_layer")]:
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-3 * scale, (T, float((a - b).abs().max()), scale)
