@@ -26,6 +26,12 @@ static inline TDrop t_drop(float p, unsigned long long seed, const unsigned long
 void t_gemm(const TRows& rows, const float* X, int ldx, int K, const float* Wt, int ldw, const float* bias, int N,
             float* Y, int ldy, int beta, hipStream_t s);                      // Y = beta*Y + X.Wt + bias   (Wt K-major, row stride ldw)
 struct TScratch { float* p; size_t floats; };                // partial results of the ordered two-stage reductions
+// deferred, batched reductions of one backward (kernels_train.hip: RedQueue): between red_begin and red_end the producers' ordered reductions are
+// recorded and run many per launch; red_flush makes everything recorded so far final (before a gradient chunk's event)
+void red_begin(const TScratch& sc, hipStream_t s);
+void red_flush();
+void red_end();
+TScratch red_acquire(const TScratch& sc);
 void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
                const TScratch& sc, hipStream_t s);                                                           // dW += A^T B
 // bf16-mixed MFMA versions (kernels_train.hip, second half).  _nt / _nn return false when the shape is not covered

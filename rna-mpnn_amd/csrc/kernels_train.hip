@@ -153,13 +153,93 @@ __global__ void k_reduce_groups(const float* __restrict__ part, int nparts, size
     for (int p = p0; p < p1; ++p) s += part[(size_t)p * stride + i];
     tmp[(size_t)g * count + i] = s;
 }
-// (the association order is a function of nparts alone: bit-reproducible.  tmp: 16 * count floats behind the partials)
+// ---- deferred, batched form (the backward of a training step): a kernel boundary costs ~4.7 us on this part and a step has ~180 of these
+// reductions, each a few microseconds of work.  While a queue is active (red_begin .. red_end, one per backward), every producer takes its
+// partial buffer from a bump arena (red_acquire) and reduce_parts only RECORDS the job; k_reduce_batch runs up to RED_MAX jobs per launch
+// (job table by value in the kernel arguments) when the arena is full, a job targets an output a pending job also targets, a gradient chunk
+// becomes final (red_flush) or the backward ends.  Per job the association order is a function of nparts alone: four contiguous runs of
+// partials summed in ascending order, then ((g0 + g1) + g2) + g3 - bit-reproducible.
+struct RedJob {
+    const float* part; float* out; float* out2; size_t stride;
+    int nparts, count, cols, ld_out, split_at, cols_keep, out2_keep, wrap_rows, wrap_shift, blk0;
+};
+#define RED_MAX 48
+struct RedBatch { RedJob j[RED_MAX]; int n; };
+static_assert(sizeof(RedBatch) <= 4000, "job table travels in the kernel arguments");
+__global__ void __launch_bounds__(256) k_reduce_batch(RedBatch b) {
+    __shared__ float red[4][64];
+    int jb = 0;
+    for (int t = 1; t < b.n; ++t) if ((int)blockIdx.x >= b.j[t].blk0) jb = t;      // (blk0 ascending; uniform)
+    const RedJob& J = b.j[jb];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = ((int)blockIdx.x - J.blk0) * 64 + lane;
+    const int per = (J.nparts + 3) >> 2, p0 = g * per, p1 = min(J.nparts, p0 + per);
+    float s = 0.f;
+    if (i < J.count) {
+#pragma unroll 8
+        for (int p = p0; p < p1; ++p) s += J.part[(size_t)p * J.stride + i];
+    }
+    red[g][lane] = s;
+    __syncthreads();
+    if (g != 0 || i >= J.count) return;
+    s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (i < J.split_at) {
+        const int row = i / J.cols, c = i % J.cols;
+        if (c < J.cols_keep)
+            J.out[(size_t)(J.wrap_rows ? row % J.wrap_rows : row) * J.ld_out + (J.wrap_rows ? (row / J.wrap_rows) * J.wrap_shift : 0) + c] += s;
+    } else if (i - J.split_at < J.out2_keep) J.out2[i - J.split_at] += s;
+}
+struct RedQueue {
+    bool active = false;
+    float* arena = nullptr; size_t floats = 0, used = 0;
+    hipStream_t s = nullptr;
+    RedBatch b;
+    int blocks = 0;
+};
+static thread_local RedQueue g_rq;
+static constexpr size_t RED_VIEW = (size_t)16 << 20;       // what one producer may assume (the pre-queue scratch size)
+void red_flush() {
+    RedQueue& q = g_rq;
+    if (q.active && q.b.n > 0) hipLaunchKernelGGL(k_reduce_batch, dim3(q.blocks), dim3(256), 0, q.s, q.b);
+    q.b.n = 0; q.blocks = 0; q.used = 0;
+}
+void red_begin(const TScratch& sc, hipStream_t s) {
+    RedQueue& q = g_rq;
+    const char* off = getenv("RNAMPNN_NO_RED_BATCH");      // A/B switch (read per call): one reduction launch per producer, as before
+    q.active = sc.floats >= 2 * RED_VIEW && !(off && off[0] == '1');
+    q.arena = sc.p; q.floats = sc.floats; q.used = 0; q.s = s; q.b.n = 0; q.blocks = 0;
+}
+void red_end() { red_flush(); g_rq.active = false; }
+// the scratch a producer works in: the whole buffer without a queue; with one, the free tail of the arena (flushed first if a producer's
+// worst case no longer fits)
+TScratch red_acquire(const TScratch& sc) {
+    RedQueue& q = g_rq;
+    if (!q.active || sc.p != q.arena) return sc;
+    if (q.floats - q.used < RED_VIEW) red_flush();
+    return TScratch{q.arena + q.used, RED_VIEW};
+}
 static void reduce_parts(const float* part, int nparts, size_t stride, int count, int cols, float* out, int ld_out, hipStream_t s,
                          float* tmp = nullptr, int split_at = -1, float* out2 = nullptr, int cols_keep = -1, int out2_keep = -1,
                          int wrap_rows = 0, int wrap_shift = 0) {
     if (split_at < 0) split_at = count;
     if (cols_keep < 0) cols_keep = cols;
     if (out2_keep < 0) out2_keep = count;
+    RedQueue& q = g_rq;
+    if (q.active && s == q.s && part >= q.arena && part < q.arena + q.floats) {
+        bool clash = q.b.n == RED_MAX;
+        for (int t = 0; t < q.b.n && !clash; ++t) {
+            const RedJob& J = q.b.j[t];
+            clash = J.out == out || (out2 && (J.out2 == out2 || J.out == out2)) || (J.out2 && J.out2 == out);
+        }
+        const size_t keep_used = q.used;
+        if (clash) { red_flush(); q.used = keep_used; }     // (the partials of THIS job are already in the arena: keep its extent)
+        RedJob& J = q.b.j[q.b.n++];
+        J = RedJob{part, out, out2, stride, nparts, count, cols, ld_out, split_at, cols_keep, out2_keep, wrap_rows, wrap_shift, q.blocks};
+        q.blocks += (count + 63) / 64;
+        const size_t end = (size_t)(part - q.arena) + (size_t)(nparts - 1) * stride + (size_t)count;
+        if (end > q.used) q.used = (end + 63) & ~(size_t)63;
+        return;
+    }
     if (tmp && nparts > 96) {
         const int G = 16, per = (nparts + G - 1) / G;
         hipLaunchKernelGGL(k_reduce_groups, dim3((count + 255) / 256, G), dim3(256), 0, s, part, nparts, stride, count, per, tmp);
@@ -203,7 +283,8 @@ __global__ void __launch_bounds__(256) k_tgemm_tn(TRows rows, const float* __res
     if (mB < M && kB < K) dst[(size_t)mB * K + kB] = a11;
 }
 void t_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
-               const TScratch& sc, hipStream_t s) {
+               const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     long long cap = (long long)(sc.floats / ((size_t)M * K));
     int splits = (rows.maxrows + 2047) / 2048;
     if (splits > 512) splits = 512;
@@ -226,7 +307,8 @@ __global__ void __launch_bounds__(256) k_colsum(TRows rows, const float* __restr
         part[(size_t)blockIdx.x * M + m] = s;
     }
 }
-void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc, hipStream_t s) {
+void t_colsum(const TRows& rows, const float* A, int lda, int M, float* out, const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     int nb = (int)(sc.floats / (size_t)M) - 16;
     if (nb > 512) nb = 512;
     int rpb = (rows.maxrows + nb - 1) / nb;
@@ -609,7 +691,8 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(PackInfo pk, const float* 
     }
 }
 void t_gn_bwd(const PackInfo& pk, const float* x, const float* dy, const float* scale, int t_tot, float* dx, float* dscale,
-              float* dshift, const TScratch& sc, hipStream_t s) {
+              float* dshift, const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     // per-RNA partials of (dscale, dshift), added in RNA order (needs B * 256 floats of scratch)
     const int nsplit = (pk.T + GN_SPLIT_ROWS - 1) / GN_SPLIT_ROWS;
     const size_t need = (size_t)pk.B * 256 + (size_t)pk.B * nsplit * 512;
@@ -1496,7 +1579,8 @@ __global__ void __launch_bounds__(256) k_mm_tn(TRows rows, const float* __restri
         }
 }
 void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* B, int ldb, int K, float* dW, int ldw,
-                const TScratch& sc, bool actB, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
+                const TScratch& sc_in, bool actB, const TDrop& dr, unsigned site, float* dbias, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     const size_t mk = (size_t)M * K;
     const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
     long long cap = (long long)((sc.floats - (size_t)520 * M) / mk) - 16;   // behind the partials: 16 * mk floats for the two-level reduction, 520 * M for the column sums
@@ -1524,7 +1608,8 @@ void tm_gemm_tn(const TRows& rows, const float* A, int lda, int M, const float* 
 // The node-side weight gradients of a factored first Linear in ONE product: [dWa ; dWb] = [dP | dQ]^T h (256 x 128), db1 = colsum(dP).
 // gw0 = the [128][384] gradient of the Linear's weight ([Wa | Wb | Wc] blocks): rows 0..127 of the product go to columns 0..127, rows
 // 128..255 to columns 128..255 of the same 128 output rows (the reduction's wrap).
-void tm_gemm_tn_pq(const TRows& rows, const float* dpq, const float* h, float* gw0, float* db1, const TScratch& sc, hipStream_t s) {
+void tm_gemm_tn_pq(const TRows& rows, const float* dpq, const float* h, float* gw0, float* db1, const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     const int M = 256, K = 128;
     const size_t mk = (size_t)M * K, pstride = mk + M;
     long long cap = (long long)(sc.floats / pstride) - 16;
@@ -2085,8 +2170,9 @@ __global__ void __launch_bounds__(256, 3) k_emm_tn(TRows rows, const tb16* __res
             for (int i = 0; i < 16; ++i) dst[(size_t)(64 * wr + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 128 + col] = acc[a][b][i];
         }
 }
-void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc, bool actB, const TDrop& dr,
+void te_gemm_tn(const TRows& rows, const tb16* A, const tb16* B, float* dW, int ldw, const TScratch& sc_in, bool actB, const TDrop& dr,
                 unsigned site, float* dbias, hipStream_t s, int cols_keep) {
+    const TScratch sc = red_acquire(sc_in);
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
     int splits = (rows.maxrows + 1023) / 1024;
@@ -2411,7 +2497,8 @@ __global__ void __launch_bounds__(256, 2) k_emm_bwd1(TRows rows, const tb16* __r
 }
 // dW[128][ldw_out] += dY^T X,  DE += dY . W       (W [128 out][ldw]: the Wc block of a first Linear)
 void te_gemm_bwd1(const TRows& rows, const tb16* dY, const tb16* X, tb16* DE, const float* W, int ldw, float* dW, int ldw_out,
-                  const TScratch& sc, hipStream_t s) {
+                  const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
     int splits = (rows.maxrows + 511) / 512;                 // >= 8 tiles per workgroup; fills the chip from ~130 K rows on
@@ -2527,7 +2614,8 @@ __global__ void __launch_bounds__(512, 1) k_emm_bwd1x2(TRows rows, const tb16* _
 }
 // dW1[128][ldw_out] += dY1^T X, dW2 += dY2^T X, DE += dY1 . W1 + dY2 . W2      (W1, W2 [128 out][ldw]: the Wc blocks of the two first Linears)
 void te_gemm_bwd1x2(const TRows& rows, const tb16* dY1, const tb16* dY2, const tb16* X, tb16* DE, const float* W1, const float* W2, int ldw,
-                    float* dW1, float* dW2, int ldw_out, const TScratch& sc, hipStream_t s) {
+                    float* dW1, float* dW2, int ldw_out, const TScratch& sc_in, hipStream_t s) {
+    const TScratch sc = red_acquire(sc_in);
     const size_t mk = 128 * 128, pstride = 2 * mk;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / pstride) - 16;
     int splits = (rows.maxrows + 1023) / 1024;               // >= 16 tiles per workgroup
@@ -2544,7 +2632,8 @@ void te_gemm_bwd1x2(const TRows& rows, const tb16* dY1, const tb16* dY2, const t
 }
 // dW[128][ldw_out] += dY^T drop(gelu(PRE)), dbias += colsum(dY), DX = (dY . W) gelu'(PRE) mask        (W [128 out][ldw] as nn.Linear stores it)
 void te_gemm_bwd2(const TRows& rows, const tb16* dY, const tb16* PRE, tb16* DX, const float* W, int ldw, float* dW, int ldw_out,
-                  const TScratch& sc, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from) {
+                  const TScratch& sc_in, const TDrop& dr, unsigned site, float* dbias, hipStream_t s, const EBwd2Src* from) {
+    const TScratch sc = red_acquire(sc_in);
     const size_t mk = 128 * 128;
     long long cap = (long long)((sc.floats - (size_t)800 * 128) / mk) - 16;
     int splits = (rows.maxrows + 511) / 512;                 // >= 8 tiles per workgroup; fills the chip from ~130 K rows on
