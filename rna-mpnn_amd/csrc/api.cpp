@@ -431,7 +431,7 @@ static void finalize_chain(rnampnn_ctx* c, const Chain& ch, const std::vector<Li
         const Lin& l = layers[i];
         bool last = i + 1 == layers.size();
         int K = i == 0 ? ch.K0 : ch.H, N = last ? ch.NOUT : ch.H;
-        launch_build_chain_image(rawp(c, l.w), l.in, K, N, l.out, i == 0 ? 1 : 0, dst, s);
+        launch_build_chain_image(rawp(c, l.w), l.in, K, N, l.out, i == 0 ? 0 : (last ? 2 : 1), dst, s);
         dst += (size_t)(N / 32) * (K / 16) * 512;
     }
     // derived arena was zeroed: bias beyond the real outputs stays 0
@@ -700,7 +700,6 @@ static int begin_run(Run& r, rnampnn_handle h, const float* mask, int B, int T, 
         add(r.w.pq_e + Nmax * 256, 256 * sizeof(float));
         add(r.w.pq_m + Nmax * 256, 256 * sizeof(float));
     }
-    if (!cu_seqlens && launch_prepare_small(mask, r.pk, z, r.s)) return RNAMPNN_OK;
     if (cu_seqlens) launch_lengths_from_cu(cu_seqlens, r.pk, r.s);
     else launch_lengths(mask, r.pk, r.s);
     launch_zero_regions(z, r.s);

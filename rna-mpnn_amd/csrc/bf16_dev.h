@@ -114,6 +114,23 @@ __device__ __forceinline__ f16x4 phi4s(f16x4 y) {
     q = __builtin_elementwise_fma(q, s, h4(RN_QS0));
     return clamp01h(__builtin_elementwise_fma(y, q, h4(0.5f)));
 }
+// The same in the scaled domain of the node FFN chains with FIVE coefficients (the accuracy of phi4_hi at the instruction count of phi4s + 1):
+// y = a x, a = 1 / sqrt(11.5) (kGAn), Phi(x) = clamp01(1/2 + y Qn(clamp01(y^2))), Qn_i = c_i 11.5^i / a with phi4_hi's c_i.  The chain's weight
+// image carries the factors (first Linear x a, last Linear / a, biases of all but the last x a: api.cpp finalize_chain, k_ffn_chain).
+static constexpr float kGAn = 0.294883912f, kGAni = 3.391164992f;
+#define RN_QN0 1.33730881f
+#define RN_QN1 -2.33529568f
+#define RN_QN2 3.02046204f
+#define RN_QN3 -2.15521932f
+#define RN_QN4 0.63268071f
+__device__ __forceinline__ f16x4 phi5n(f16x4 y) {
+    const f16x4 s = clamp01h(y * y);
+    f16x4 q = __builtin_elementwise_fma(s, h4(RN_QN4), h4(RN_QN3));
+    q = __builtin_elementwise_fma(q, s, h4(RN_QN2));
+    q = __builtin_elementwise_fma(q, s, h4(RN_QN1));
+    q = __builtin_elementwise_fma(q, s, h4(RN_QN0));
+    return clamp01h(__builtin_elementwise_fma(y, q, h4(0.5f)));
+}
 __device__ __forceinline__ f16x2 phi2s(f16x2 y) {
     const f16x2 s = clamp01h(y * y);
     f16x2 q = __builtin_elementwise_fma(s, h2(RN_QS3), h2(RN_QS2));

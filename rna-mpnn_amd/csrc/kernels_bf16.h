@@ -37,7 +37,7 @@ void launch_resmpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, c
                          const bf16_t* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm, float* agg, const float* h_res, hipStream_t s);
 
 // fused FFN chain  X -> Linear(K0,H)+GELU -> NH x [Linear(H,H)+GELU] -> Linear(H,NOUT)  (see kernels_bf16.hip)
-void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s);
+void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int position, bf16_t* dst, hipStream_t s);   // position: 0 first, 1 hidden, 2 last Linear
 static inline size_t chain_image_bytes(int K0, int H, int NH, int NOUT) {
     return ((size_t)(H / 32) * (K0 / 16) + (size_t)NH * (H / 32) * (H / 16) + (size_t)(NOUT / 32) * (H / 16)) * 1024;
 }

@@ -976,7 +976,7 @@ struct ChainW {
 // raw s_barrier (a __syncthreads() would drain the ring: cdna guide, "Pipelining across barriers").
 #define CH_RING 4
 // timing ablations of k_ffn_chain (WRONG results; tools/build_mpnn_variant.sh with RN_VARIANT_SRC=kernels_bf16.hip passes -DRN_EXPERIMENTS)
-#if !defined(RN_EXPERIMENTS) && (defined(CH_EXP_NODMA) || defined(CH_EXP_NOGELU) || defined(CH_EXP_NOLDS) || defined(CH_EXP_NOBAR))
+#if !defined(RN_EXPERIMENTS) && (defined(CH_EXP_NODMA) || defined(CH_EXP_NOGELU) || defined(CH_EXP_NOLDS) || defined(CH_EXP_NOBAR) || defined(CH_GRANULES1))
 #error "k_ffn_chain ablations need -DRN_EXPERIMENTS"
 #endif
 #ifndef CH_GELU
@@ -1034,7 +1034,8 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
 #else
             const f16x4 x = cvt_h4(acc[2 * t], acc[2 * t + 1], acc[8 + 2 * t], acc[8 + 2 * t + 1]);
 #if CH_GELU == 1
-            const f16x4 g = x * phi4_hi(x);        // packed-f16 GELU, five-coefficient Phi (1.2e-3): what follows a node chain is a GraphNormalization
+            const f16x4 g = x * phi5n(x);          // packed-f16 GELU in the chain's scaled domain (x = a pre-activation), five-coefficient Phi (1.2e-3):
+                                                   // what follows a node chain is a GraphNormalization, which amplifies the approximation error
 #else
             const f16x4 g = x * phi4(x);           // packed-f16 GELU (phi4), hidden activations stay f16: as in the edge kernels
 #endif
@@ -1067,7 +1068,8 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
 #endif
                 if constexpr (c + 3 < NCH_T && (m & 3) == 1) chain_issue_piece(img, ring, c + 3, tid, m >> 2);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ob > 0) {                        // granules of the previous block behind this block's MFMAs
+                if constexpr (ob > 0) {                        // the previous block's activation arithmetic behind the MFMAs of this one
+#ifndef CH_GRANULES1     /* (default: one quarter of the previous tile at a time) */
                     if constexpr (NKS >= 4) {
                         if constexpr ((ks + 1) % (NKS / 4) == 0)
                             granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (ks + 1) / (NKS / 4) - 1>{});
@@ -1075,6 +1077,11 @@ __device__ __forceinline__ void chain_layer(const u32x4* __restrict__ img, u32x4
                         granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (2 * ks) & 3>{});
                         granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, std::integral_constant<int, (2 * ks + 1) & 3>{});
                     }
+#else
+                    // experiment CH_GRANULES1: all four quarters in one place (eight independent word chains) - 63.0 against 62.3 us: no gain
+                    if constexpr (ks == (NKS >= 2 ? NKS / 2 - 1 : 0))
+                        static_for<4>([&](auto tc) { granule(prev, std::integral_constant<int, (ob > 0 ? ob - 1 : 0)>{}, tc); });
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -1108,7 +1115,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
         for (int t = 0; t < NBL; ++t) {
             const int idx = tid + 256 * t;                     // position in the concatenated [layer][channel] list
             const int l = idx / H < NH + 1 ? idx / H : NH + 1, i = idx - l * H;
-            bv[t] = (idx < (NH + 1) * H + NOUT) ? w.bias[l][i] : 0.f;
+            bv[t] = (idx < (NH + 1) * H + NOUT) ? (CH_GELU == 1 && l < NH + 1 ? kGAn : 1.f) * w.bias[l][i] : 0.f;      // (scaled domain: hidden biases x a)
         }
 #pragma unroll
         for (int t = 0; t < NBL; ++t) if (tid + 256 * t < (NH + 1) * H + NOUT) bias_lds[tid + 256 * t] = bv[t];
@@ -1149,7 +1156,7 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
 
 // chain weight image: layer with K inputs, N outputs (rows >= n_real are zero): chunks [ob][ks][lane][8];
 // first layer: k natural (16 ks + 8h + j); later layers: ks = 2mb + s' <-> channel 32mb + 16h + 8s' + j
-__global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, int K, int N, int n_real, int first,
+__global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, int K, int N, int n_real, int first, float wscale,
                                     bf16_t* __restrict__ dst) {
     int id = blockIdx.x * blockDim.x + threadIdx.x;
     int nks = K / 16;
@@ -1159,12 +1166,14 @@ __global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, 
     int row = ch_nat(ob, r);
     int col = first ? 16 * ks + 8 * h + j : 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + j;
     const float wv = (row < n_real && col < K_real) ? wraw[(size_t)row * K_real + col] : 0.f;
-    dst[id] = __builtin_bit_cast(bf16_t, (_Float16)wv);      // every layer consumes f16 operands (the first one too since round 4: the input rows keep 11
+    dst[id] = __builtin_bit_cast(bf16_t, (_Float16)(wscale * wv));      // every layer consumes f16 operands (the first one too since round 4: the input rows keep 11
                                                              // significand bits instead of 8 - see tools/tap_errors.py: the GraphNorm behind the node stacks amplifies input rounding)
 }
-void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int first, bf16_t* dst, hipStream_t s) {
+// position: 0 first Linear of the chain, 1 hidden, 2 last (scaled activation domain of the chain's GELU: first x a, last / a)
+void launch_build_chain_image(const float* wraw, int K_real, int K, int N, int n_real, int position, bf16_t* dst, hipStream_t s) {
     int total = (N / 32) * (K / 16) * 512;
-    hipLaunchKernelGGL(k_build_chain_image, dim3((total + 255) / 256), dim3(256), 0, s, wraw, K_real, K, N, n_real, first, dst);
+    const float wscale = CH_GELU == 1 ? (position == 0 ? kGAn : position == 2 ? kGAni : 1.f) : 1.f;
+    hipLaunchKernelGGL(k_build_chain_image, dim3((total + 255) / 256), dim3(256), 0, s, wraw, K_real, K, N, n_real, position == 0 ? 1 : 0, wscale, dst);
 }
 
 // returns 0 when the (K0, H, NH, NOUT) shape has a fused kernel, 1 otherwise (caller falls back to GEMMs)
@@ -1423,22 +1432,28 @@ __device__ __forceinline__ float half_wave_sum2(float a, float b) {
     v += dpp_f32<0x140, 0xf>(v);       // row_mirror
     return v;
 }
-template <int NJOBS, int NW>
-__global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
+// NB row blocks of 32 residues per workgroup, one wave each.  (Two waves per row block - one job / one P-or-Q half each, 2 NB waves over the four
+// SIMDs - measured slower at the C2 lengths: 27.3 against 24.7 us; twice the row loads and ten waves at the barriers cost more than the better
+// spread of the MFMAs gains.)
+template <int NJOBS, int NB>
+__global__ void __launch_bounds__(NB * 64) k_node_update_rna(PackInfo pk, const float* __restrict__ x, const float* __restrict__ add,
         const float* __restrict__ scale, const float* __restrict__ shift, int t_tot, float* __restrict__ h_out, PqJob j0, PqJob j1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* img = reinterpret_cast<u32x4*>(smem);
     float* lds_bias = reinterpret_cast<float*>(smem + NJOBS * 65536);      // [2][128]
-    float* lds_part = lds_bias + 256;                                       // [NW][128] per-wave partial sums
-    float* lds_mean = lds_part + NW * 128;                                  // [128]
+    constexpr int NW = NB;
+    float* lds_part = lds_bias + 256;                                       // [NB][128] per-row-block partial sums
+    float* lds_mean = lds_part + NB * 128;                                  // [128]
     float* lds_ab = lds_mean + 128;                                         // [128] a | [128] b
     const int b = blockIdx.x;
     const int n = pk.len[b];
     if (n <= 0) return;
     const int base = pk.cu[b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int lrow = 32 * wave + r;
+    const int rb = wave;                                     // row block
+    const int lrow = 32 * rb + r;
     const bool ok = lrow < n;
+    const bool own = ok;
     const int row = base + (ok ? lrow : 0);
     f32x4 vx[8][2], va[8][2];
 #pragma unroll
@@ -1472,8 +1487,8 @@ __global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const 
             for (int i = 0; i < 4; ++i) { t0[i] = half_wave_sum2(value(s, 0, i), value(s + 4, 0, i)); t1[i] = half_wave_sum2(value(s, 1, i), value(s + 4, 1, i)); }
             if ((r & 15) == 0) {
                 const int sb = s + (r >> 4) * 4;
-                *reinterpret_cast<f32x4*>(lds_part + wave * 128 + 16 * sb + 8 * h) = t0;
-                *reinterpret_cast<f32x4*>(lds_part + wave * 128 + 16 * sb + 8 * h + 4) = t1;
+                *reinterpret_cast<f32x4*>(lds_part + rb * 128 + 16 * sb + 8 * h) = t0;
+                *reinterpret_cast<f32x4*>(lds_part + rb * 128 + 16 * sb + 8 * h + 4) = t1;
             }
         }
     };
@@ -1484,7 +1499,7 @@ __global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const 
     };
     const float fn = (float)n;
     // pass 1: mean
-    reduce_rows([&](int s, int p, int i) { return ok ? vx[s][p][i] : 0.f; });
+    reduce_rows([&](int s, int p, int i) { return own ? vx[s][p][i] : 0.f; });
     __syncthreads();
     float mean_c = 0.f;
     if (tid < 128) { mean_c = combine() / fn; lds_mean[tid] = mean_c; }
@@ -1496,7 +1511,7 @@ __global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const 
         mu[s][1] = *reinterpret_cast<const f32x4*>(lds_mean + 16 * s + 8 * h + 4);
     }
     // pass 2: squared deviations of the valid rows; the T - n padded rows enter as (0 - mean)^2
-    reduce_rows([&](int s, int p, int i) { const float d = vx[s][p][i] - mu[s][p][i]; return ok ? d * d : 0.f; });
+    reduce_rows([&](int s, int p, int i) { const float d = vx[s][p][i] - mu[s][p][i]; return own ? d * d : 0.f; });
     __syncthreads();
     if (tid < 128) {
         const float sq = combine(), pad = (float)(t_tot - n);
@@ -1522,7 +1537,7 @@ __global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const 
     __builtin_amdgcn_sched_barrier(0);
     dma_landed();
     __builtin_amdgcn_sched_barrier(0);
-    if (ok && h_out) {
+    if (own && h_out) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int c0 = 16 * s + 8 * h;
@@ -1531,7 +1546,7 @@ __global__ void __launch_bounds__(NW * 64) k_node_update_rna(PackInfo pk, const 
         }
     }
     __syncthreads();
-    if (wave >= nwb) return;                                // (no barrier below)
+    if (rb >= nwb) return;                                  // (no barrier below)
 #pragma unroll
     for (int jb = 0; jb < NJOBS; ++jb) {
         const PqJob& jbq = jb == 0 ? j0 : j1;
@@ -1587,15 +1602,15 @@ void launch_node_update(const PackInfo& pk, const float* x, const float* add, co
     // are computed inside the update kernel (RNAMPNN_NODE_UPDATE_RNA=0: the two-launch form; read per call)
     static const auto rna_form_env = []() { const char* v = getenv("RNAMPNN_NODE_UPDATE_RNA"); return !(v && v[0] == '0'); };
     if (scale && pk.T >= 48 && pk.T <= 256 && rna_form_env()) {
-#define NU_RNA(J, W)                                                                                                            \
+#define NU_RNA(J, NBK)                                                                                                          \
         do {                                                                                                                    \
             static DevAttr attr;                                                                                                \
-            constexpr size_t lds = (size_t)(J) * 65536 + 1024 + (W) * 512 + 3 * 512;                                            \
-            ensure_dyn_lds((const void*)k_node_update_rna<J, W>, lds, attr);                                                    \
-            hipLaunchKernelGGL((k_node_update_rna<J, W>), dim3(pk.B), dim3((W) * 64), lds, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1); \
+            constexpr size_t lds = (size_t)(J) * 65536 + 1024 + (NBK) * 512 + 3 * 512;                                          \
+            ensure_dyn_lds((const void*)k_node_update_rna<J, NBK>, lds, attr);                                                  \
+            hipLaunchKernelGGL((k_node_update_rna<J, NBK>), dim3(pk.B), dim3((NBK) * 64), lds, s, pk, x, add, scale, shift, t_tot, h_out, j0, j1); \
         } while (0)
-        if (njobs == 1) { if (pk.T <= 128) NU_RNA(1, 4); else NU_RNA(1, 8); }
-        else { if (pk.T <= 128) NU_RNA(2, 4); else NU_RNA(2, 8); }
+        if (njobs == 1) { if (pk.T <= 128) NU_RNA(1, 4); else if (pk.T <= 160) NU_RNA(1, 5); else NU_RNA(1, 8); }
+        else { if (pk.T <= 128) NU_RNA(2, 4); else if (pk.T <= 160) NU_RNA(2, 5); else NU_RNA(2, 8); }
 #undef NU_RNA
         return;
     }

@@ -132,36 +132,6 @@ void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipSt
     hipLaunchKernelGGL(k_lengths_from_cu, dim3(1), dim3(1024), 0, s, cu_seqlens, pk.B, pk.T, pk.Nmax, pk.len, pk.cu);
 }
 
-// lengths + prefix sum + the zero rows in ONE launch for batches whose mask one workgroup reads in a few microseconds (a kernel boundary costs
-// ~4.7 us on this part: three launches -> one, same integers)
-__global__ void __launch_bounds__(1024) k_prepare_small(const float* __restrict__ mask, int B, int T, int* __restrict__ len, int* __restrict__ cu,
-                                                        ZeroRegions z) {
-    __shared__ int wave_tot[16];
-    __shared__ int len_s[1024];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int b = wave; b < B; b += 16) {
-        float sm = 0.f;
-        for (int t = lane; t < T; t += WAVE) sm += mask[(size_t)b * T + t];
-        sm = wave_sum(sm);
-        if (lane == 0) len_s[b] = (int)(sm + 0.5f);
-    }
-    for (int g = 0; g < z.n; ++g) {
-        unsigned* p = reinterpret_cast<unsigned*>(z.ptr[g]);
-        for (unsigned i = tid; i < z.words[g]; i += 1024) p[i] = 0u;
-    }
-    __syncthreads();
-    const int v = tid < B ? len_s[tid] : 0;
-    int total;
-    const int run = block_exclusive_scan_1024(v, wave_tot, &total);
-    if (tid < B) { len[tid] = v; cu[tid] = run; }
-    if (tid == 0) cu[B] = total;
-}
-bool launch_prepare_small(const float* mask, const PackInfo& pk, const ZeroRegions& z, hipStream_t s) {
-    if (pk.B > 1024 || (size_t)pk.B * pk.T > 65536) return false;
-    hipLaunchKernelGGL(k_prepare_small, dim3(1), dim3(1024), 0, s, mask, pk.B, pk.T, pk.len, pk.cu, z);
-    return true;
-}
-
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s) {
     hipLaunchKernelGGL(k_lengths, dim3(pk.B), dim3(WAVE), 0, s, mask, pk.B, pk.T, pk.len);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, pk.len, pk.B, pk.cu);

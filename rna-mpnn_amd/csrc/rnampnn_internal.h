@@ -58,7 +58,6 @@ void launch_zero_regions(const ZeroRegions& z, hipStream_t s);
 void launch_zero_bytes(void* ptr, size_t bytes, hipStream_t s, int site = 0x80);                    // kernel, not a memset node (hipGraph-safe); ptr 16-byte aligned
 void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);   // kernel copy, 16-byte aligned, bytes % 16 == 0
 void launch_lengths(const float* mask, const PackInfo& pk, hipStream_t s);
-bool launch_prepare_small(const float* mask, const PackInfo& pk, const ZeroRegions& z, hipStream_t s);   // lengths + scan + zero rows in one launch; false: batch too large
 void launch_lengths_from_cu(const int32_t* cu_seqlens, const PackInfo& pk, hipStream_t s);
 void launch_geom(const float* coords, const PackInfo& pk, float* raw_out, float* raw_p, float* geom, float* geomh, hipStream_t s);
 int  launch_knn(const float* coords, const PackInfo& pk, int k, int* nbr, int64_t* edge_index_out, hipStream_t s);
