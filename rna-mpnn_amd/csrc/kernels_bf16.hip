@@ -1154,204 +1154,6 @@ __global__ void __launch_bounds__(256, 1) k_ffn_chain(const int* __restrict__ nt
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// The same chain with TWO waves per SIMD (round 4).  k_ffn_chain's wave is alone on its SIMD (its 404 registers hold a row block's input AND output
-// activations), so its matrix, vector and DMA-issue times add (docs/experiments.md R4.7: 37 + 17 + 11 us).  Here a PAIR of waves owns a 32-row block
-// and splits K: wave A holds k-steps 0..15 of the 512-wide operand (64 VGPRs), wave B 16..31.  Per pair of output blocks (a <= 7 of A's set, b = a + 8
-// of B's): step 1 - A accumulates its K-half of block b, B its K-half of block a, each leaves the f32 partial tile in its 4 KiB LDS slot; step 2 - the
-// owner starts from the partner's partial (the accumulator's initial value) and adds its own K-half.  Block a's GELU'd output IS k-steps 2a, 2a + 1 of
-// the next operand - A's own half - so no activation ever changes wave: ~190 registers, 8 waves per CU, one 4 KiB LDS write + read per 32 MFMAs.
-// The first Linear (K0 <= 256) is not split: both waves hold the whole input and compute their own eight output blocks.
-// Weight stream: the same image; a ring slot (32 KiB) holds 16 fragments for each wave group per step of 16 MFMAs; every wave issues 4 of the slot's 32
-// LDS-DMA pieces (half the DMA issue per wave), three steps ahead.  Sums run in another order than k_ffn_chain's (K-halves): equal to f32 rounding.
-struct Chain2Step { int f0[2]; };                  // first fragment (index into the image) of wave group 0 / 1 for the step's 16 MFMAs
-template <int K0, int H, int NH, int NOUT>
-__host__ __device__ constexpr int chain2_total_steps() { return (H / 64) * (K0 / 16) / 16 + NH * (H / 32) + ((NOUT / 32) >= 2 ? NOUT / 32 : 2); }
-template <int K0, int H, int NH, int NOUT>
-__host__ __device__ constexpr Chain2Step chain2_step(int gs) {
-    constexpr int NKS0 = K0 / 16, HB = H / 32, HK = H / 16, OBL = NOUT / 32, PL = OBL >= 2 ? OBL / 2 : 1;
-    constexpr int F0 = (HB / 2) * NKS0, S0 = F0 / 16;
-    if (gs < S0) return Chain2Step{{16 * gs, F0 + 16 * gs}};
-    gs -= S0;
-    int base = HB * NKS0;
-    for (int l = 0; l < NH; ++l) {
-        if (gs < HB) {
-            const int p = gs >> 1, ph = gs & 1;
-            return ph == 0 ? Chain2Step{{base + (HB / 2 + p) * HK, base + p * HK + HK / 2}} : Chain2Step{{base + p * HK, base + (HB / 2 + p) * HK + HK / 2}};
-        }
-        gs -= HB; base += HB * HK;
-    }
-    const int p = gs >> 1, ph = gs & 1, bb = OBL >= 2 ? PL + p : p;      // (one output block: group 0 / 1 fetch a fragment run they do not use in their idle step)
-    return ph == 0 ? Chain2Step{{base + bb * HK, base + p * HK + HK / 2}} : Chain2Step{{base + p * HK, base + bb * HK + HK / 2}};
-}
-template <int K0, int H, int NH, int NOUT>
-__global__ void __launch_bounds__(512, 1) k_ffn_chain2(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx,
-        const float* __restrict__ X2, int ldx2, ChainW w, float* __restrict__ Y, int ldy, int n_valid) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [ring 4 x 32 KiB][8 partial-tile slots x 4 KiB]
-    u32x4* ring = reinterpret_cast<u32x4*>(smem);
-    f32x4* slots = reinterpret_cast<f32x4*>(smem + CH_RING * 32768);
-    static_assert(H == 512 && K0 % 16 == 0 && K0 <= 256 && NOUT % 32 == 0 && ((H / 64) * (K0 / 16)) % 16 == 0, "shapes of the K-split pair form");
-    const int ntot = *ntot_p;
-    const int row_blk = blockIdx.x * 128;
-    if (row_blk >= ntot) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int rb = wave & 3, hf = wave >> 2;                  // row block of the pair; K-half / output-block set of this wave
-    const int row = row_blk + 32 * rb + r;
-    const bool row_ok = row < ntot;
-    constexpr int TOTAL = chain2_total_steps<K0, H, NH, NOUT>();
-    constexpr int NKS0 = K0 / 16, HB = H / 32, HK = H / 16, OBL = NOUT / 32, PL = OBL >= 2 ? OBL / 2 : 1;
-    u32x4 x0[NKS0];                                           // the whole input row block of the first Linear
-    {
-        const int rr = row_ok ? row : ntot - 1;
-        f32x4 v0[NKS0], v1[NKS0];
-#pragma unroll
-        for (int s = 0; s < NKS0; ++s) {
-            const int kk = 16 * s + 8 * h;
-            const float* src = (K0 > 128 && kk >= 128) ? X2 + (size_t)rr * ldx2 + (kk - 128) : X + (size_t)rr * ldx + kk;
-            v0[s] = *reinterpret_cast<const f32x4*>(src);
-            v1[s] = *reinterpret_cast<const f32x4*>(src + 4);
-        }
-#pragma unroll
-        for (int s = 0; s < NKS0; ++s)
-            x0[s] = u32x4{p_pack2(v0[s][0], v0[s][1]), p_pack2(v0[s][2], v0[s][3]), p_pack2(v1[s][0], v1[s][1]), p_pack2(v1[s][2], v1[s][3])};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the counted waits below see LDS-DMA pieces and bias loads only)
-    const u32x4* img = reinterpret_cast<const u32x4*>(w.img);
-    // the four DMA pieces of this wave for global step gs: slot fragments wave, wave + 8 (wave group 0), wave + 16, wave + 24 (group 1)
-    auto issue = [&](auto gsc) {
-        constexpr int gs = decltype(gsc)::value;
-        constexpr Chain2Step st = chain2_step<K0, H, NH, NOUT>(gs);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sf = wave + 8 * i, f = sf & 15;
-            const u32x4* src = img + ((size_t)(i < 2 ? st.f0[0] : st.f0[1]) + f) * 64 + lane;
-            u32x4* dst = ring + (gs % CH_RING) * 2048 + sf * 64;        // wave-uniform base; the DMA adds lane * 16
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    issue(std::integral_constant<int, 0>{});
-    if constexpr (TOTAL > 1) issue(std::integral_constant<int, 1>{});
-    if constexpr (TOTAL > 2) issue(std::integral_constant<int, 2>{});
-    float* yrow = Y + (size_t)row * ldy;
-    f32x4* my_slot = slots + wave * 256 + lane;               // this wave's partial tile: 4 x (64 lanes x 16 B)
-    const f32x4* peer_slot = slots + (wave ^ 4) * 256 + lane;
-    // the start of a step: its slot has landed (own pieces: counted wait; the others': barrier), and everyone has left the slot the next issue refills
-    auto step_begin = [&](auto gsc) {
-        constexpr int gs = decltype(gsc)::value;
-        // (lgkmcnt: this wave's partial tile of the previous step is in LDS before anyone passes the barrier)
-        if constexpr (TOTAL - 1 - gs >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if constexpr (TOTAL - 1 - gs == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if constexpr (gs + 3 < TOTAL) issue(std::integral_constant<int, gs + 3>{});
-    };
-    // accumulator start = (scaled) bias of block ob, accumulator order.  SCALAR loads of the block's 32 values (ob is wave-uniform) and a select per
-    // lane half: a vector load here would make the compiler drain the LDS-DMA pieces in flight at its first use (vmcnt counts both)
-    auto bias16 = [&](const float* bias, int ob, float scale) -> f32x16 {
-        const float* p = bias + 32 * __builtin_amdgcn_readfirstlane(ob);
-        f32x16 lo, hi;                                       // (inline asm: the compiler cannot prove the bias rows read-only and would use vector loads)
-        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
-        f32x16 v;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = scale * (h ? hi[i] : lo[i]);
-        return v;
-    };
-    auto gelu_frags = [&](const f32x16& acc, u32x4& o0, u32x4& o1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f16x4 x = cvt_h4(acc[2 * q], acc[2 * q + 1], acc[8 + 2 * q], acc[8 + 2 * q + 1]);
-#if CH_GELU == 1
-            const f16x4 gl = x * phi5n(x);
-#else
-            const f16x4 gl = x * phi4(x);
-#endif
-            o0[q] = __builtin_bit_cast(unsigned, lo2(gl));
-            o1[q] = __builtin_bit_cast(unsigned, hi2(gl));
-        }
-    };
-    constexpr float kHS = CH_GELU == 1 ? kGAn : 1.f;          // hidden biases live in the scaled domain
-    u32x4 a[16], b[16];                                       // this wave's K-half of the operand, ping-pong
-    f32x16 acc;
-    // ---- first Linear: no K-split; this wave's output blocks 8 hf .. 8 hf + 7 -> its K-half of the next operand
-    {
-        constexpr int S0 = (HB / 2) * NKS0 / 16;
-        static_for<S0>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            step_begin(std::integral_constant<int, t>{});
-            const u32x4* buf = ring + (t % CH_RING) * 2048 + hf * 1024 + lane;
-            u32x4 fr[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) fr[m] = buf[m * 64];
-            static_for<16>([&](auto fc) {
-                constexpr int f = decltype(fc)::value, g = 16 * t + f, ol = g / NKS0, ks = g % NKS0;
-                if constexpr (ks == 0) acc = bias16(w.bias[0], (HB / 2) * hf + ol, kHS);
-                acc = mfma32h(fr[f & 7], x0[ks], acc);
-                if constexpr (f + 8 < 16) fr[f & 7] = buf[(f + 8) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ks == NKS0 - 1) { gelu_frags(acc, a[2 * ol], a[2 * ol + 1]); __builtin_amdgcn_sched_barrier(0); }
-            });
-        });
-    }
-    // ---- a K-split layer: NOBL output blocks (pairs p: block p owned by group 0, block PP + p by group 1; one block: group 0 owns it, group 1 only helps)
-    auto split_layer = [&](auto gs0c, auto noblc, auto lastc, const float* bias, const u32x4 (&in)[16], u32x4 (&out)[16]) {
-        constexpr int GS0 = decltype(gs0c)::value, NOBL = decltype(noblc)::value;
-        constexpr bool LAST = decltype(lastc)::value;
-        constexpr int PP = NOBL >= 2 ? NOBL / 2 : 1;
-        static_for<2 * PP>([&](auto sc) {
-            constexpr int st = decltype(sc)::value, p = st >> 1, ph = st & 1, gs = GS0 + st;
-            step_begin(std::integral_constant<int, gs>{});
-            const u32x4* buf = ring + (gs % CH_RING) * 2048 + hf * 1024 + lane;
-            // step 1 (ph 0): the PARTNER's block, start from its bias; step 2: the own block, start from the partner's partial tile
-            const int own = NOBL >= 2 ? hf * PP + p : p, other = NOBL >= 2 ? (hf ^ 1) * PP + p : p;
-            const bool idle = NOBL < 2 && ((ph == 0 && hf == 0) || (ph == 1 && hf == 1));      // (one block: group 0 has no partner block, group 1 no own one)
-            if (ph == 0) acc = bias16(bias, other, LAST ? 1.f : kHS);
-            else {
-                const f32x4 s0 = peer_slot[0], s1 = peer_slot[64], s2 = peer_slot[128], s3 = peer_slot[192];
-                acc = f32x16{s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3], s3[0], s3[1], s3[2], s3[3]};
-            }
-            u32x4 fr[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) fr[m] = buf[m * 64];
-            if (!idle) {                                     // (wave-uniform)
-                static_for<16>([&](auto fc) {
-                    constexpr int f = decltype(fc)::value;
-                    acc = mfma32h(fr[f & 7], in[f], acc);
-                    if constexpr (f + 8 < 16) fr[f & 7] = buf[(f + 8) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-            if constexpr (ph == 0) {
-                my_slot[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
-                my_slot[64] = f32x4{acc[4], acc[5], acc[6], acc[7]};
-                my_slot[128] = f32x4{acc[8], acc[9], acc[10], acc[11]};
-                my_slot[192] = f32x4{acc[12], acc[13], acc[14], acc[15]};
-            } else if constexpr (!LAST) {
-                gelu_frags(acc, out[2 * p], out[2 * p + 1]);
-            } else if (row_ok && !idle) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = 32 * own + 16 * h + 4 * q;
-                    if (c0 < n_valid) *reinterpret_cast<f32x4*>(yrow + c0) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    using std::integral_constant;
-    constexpr int S0 = (HB / 2) * NKS0 / 16;
-    if constexpr (NH == 0) {
-        split_layer(integral_constant<int, S0>{}, integral_constant<int, OBL>{}, integral_constant<bool, true>{}, w.bias[1], a, b);
-    } else if constexpr (NH == 1) {
-        split_layer(integral_constant<int, S0>{}, integral_constant<int, HB>{}, integral_constant<bool, false>{}, w.bias[1], a, b);
-        split_layer(integral_constant<int, S0 + HB>{}, integral_constant<int, OBL>{}, integral_constant<bool, true>{}, w.bias[2], b, a);
-    } else {
-        split_layer(integral_constant<int, S0>{}, integral_constant<int, HB>{}, integral_constant<bool, false>{}, w.bias[1], a, b);
-        split_layer(integral_constant<int, S0 + HB>{}, integral_constant<int, HB>{}, integral_constant<bool, false>{}, w.bias[2], b, a);
-        split_layer(integral_constant<int, S0 + 2 * HB>{}, integral_constant<int, OBL>{}, integral_constant<bool, true>{}, w.bias[3], a, b);
-    }
-}
-
 // chain weight image: layer with K inputs, N outputs (rows >= n_real are zero): chunks [ob][ks][lane][8];
 // first layer: k natural (16 ks + 8h + j); later layers: ks = 2mb + s' <-> channel 32mb + 16h + 8s' + j
 __global__ void k_build_chain_image(const float* __restrict__ wraw, int K_real, int K, int N, int n_real, int first, float wscale,
@@ -1382,15 +1184,9 @@ int launch_ffn_chain(const int* ntot, int mmax, const float* X, int ldx, const f
     for (int i = 0; i < 5; ++i) w.bias[i] = i < NH + 2 ? bias[i] : nullptr;
     dim3 grid((mmax + 127) / 128);
     const size_t lds = CH_RING * 32768 + (size_t)((NH + 1) * H + NOUT) * sizeof(float);
-    static const auto pair_env = []() { const char* v = getenv("RNAMPNN_CHAIN_PAIR"); return !(v && v[0] == '0'); };     // RNAMPNN_CHAIN_PAIR=0: one wave per SIMD (A/B; read per call)
-    const bool pair = pair_env();
-    const size_t lds2 = CH_RING * 32768 + 8 * 4096;            // k_ffn_chain2: ring + the pairs' partial-tile slots (biases come from global memory)
 #define RN_CHAIN(k0, hh, nh, no) \
     if (K0 == k0 && H == hh && NH == nh && NOUT == no) { \
-        static DevAttr attr, attr2; \
-        if (pair) { \
-            ensure_dyn_lds((const void*)k_ffn_chain2<k0, hh, nh, no>, lds2, attr2); \
-            hipLaunchKernelGGL((k_ffn_chain2<k0, hh, nh, no>), grid, dim3(512), lds2, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; } \
+        static DevAttr attr; \
         ensure_dyn_lds((const void*)k_ffn_chain<k0, hh, nh, no>, lds, attr); \
         hipLaunchKernelGGL((k_ffn_chain<k0, hh, nh, no>), grid, dim3(256), lds, s, ntot, X, ldx, X2, ldx2, w, Y, ldy, n_valid); return 0; }
     RN_CHAIN(128, 512, 2, 128)

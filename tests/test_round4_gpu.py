@@ -167,27 +167,3 @@ def test_node_update_with_in_kernel_graphnorm_statistics_matches_the_two_launch_
         for a, b in [(new, old)] + [(taps_n[k], taps_o[k]) for k in ("h_layer", "e_layer")]:
             scale = float(b.abs().max())
             assert float((a - b).abs().max()) <= 2e-3 * scale, (T, float((a - b).abs().max()), scale)
-
-
-def test_pair_form_of_the_node_ffn_chains_matches_the_one_wave_form(monkeypatch):
-    """The node FFN chains (emb / post-fusion FFN, RawFFN, Readout: functional.py:51-90,93-202) run with two waves per SIMD (k_ffn_chain2: a wave
-    pair per 32-row block splits K, the f32 partial tiles cross through LDS); RNAMPNN_CHAIN_PAIR=0 runs k_ffn_chain (one wave per SIMD).  Same
-    f16 operands and f32 accumulation, another summation order (K-halves): h0, embedding and logits agree to f32-rounding level (the f16
-    rounding of a hidden activation can flip on a last-bit difference, hence 1e-3 of the scale, not 1e-6) - ragged batch (row blocks that end
-    inside a tile), more than one 128-row tile, RNAs of 1 residue."""
-    from rnampnn.utils import synth
-    for T, lens in ((64, [64, 20, 47, 33, 5, 58, 31, 1]), (150, [150, 97, 1, 129, 33, 140, 77, 101, 120])):
-        model = _small("bf16", num_res_mpnn_layers=2, padding_len=T).eval()
-        coords, mask, _ = synth.synth_batch(lens, first_index=23)
-        c, m = torch.from_numpy(coords), torch.from_numpy(mask)
-        pair = model(c, m).clone()
-        emb_p = model.embedding(c, m).clone()
-        taps_p = {k: v.clone() for k, v in model.forward_taps(c, m, ["h0"], tap_layer=0).items() if torch.is_tensor(v)}
-        monkeypatch.setenv("RNAMPNN_CHAIN_PAIR", "0")
-        one = model(c, m).clone()
-        emb_o = model.embedding(c, m).clone()
-        taps_o = {k: v.clone() for k, v in model.forward_taps(c, m, ["h0"], tap_layer=0).items() if torch.is_tensor(v)}
-        monkeypatch.delenv("RNAMPNN_CHAIN_PAIR")
-        assert torch.isfinite(pair).all() and (pair[mask == 0] == 0).all() and not torch.equal(pair, one)
-        for x, y in ((pair, one), (emb_p, emb_o), (taps_p["h0"], taps_o["h0"])):
-            assert float((x - y).abs().max()) <= 1e-3 * float(y.abs().max()), (T, float((x - y).abs().max()), float(y.abs().max()))
