@@ -637,8 +637,8 @@ def test_edge_case_shapes(precision):
     assert (out["edge_index"] == -1).all()
     ref, _ = _oracle(hp, sd, c1, m1)
     assert (out["logits"].cpu() - ref).abs().max() < tol
-    # (b) k = 1 and k = 32 on a ragged batch
-    for k in (1, 32):
+    # (b) k = 1, k = 20 (a dozen padding slots per 32-slot block of the fused kernels) and k = 32 on a ragged batch
+    for k in (1, 20, 32):
         hpk = dict(DEFAULT_HPARAMS, num_res_neighbours=k, padding_len=48, num_res_mpnn_layers=2)
         ck, mk, _ = synth.synth_batch([40, 9, 33], first_index=60)
         mdl, sdk = _model(hpk, state_dict_shapes(hpk), precision)
