@@ -1056,59 +1056,9 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const int* __restrict__ ntot_p
     }
 }
 
-// The same Linear for K <= 32 and N = 128 (`raw_project`, feature.py:183: 28 -> 128): 128 rows per workgroup, the thread's weight column in
-// registers, X rows broadcast from LDS; the generic kernel's 32-row tiles made it a 19 us launch for 0.2 GFLOP.  Same FMA order (bias, then k
-// ascending): bit-identical to k_gemm_f32.
-__global__ void __launch_bounds__(256) k_gemm_f32_k32(const int* __restrict__ ntot_p, const float* __restrict__ X, int ldx, int K,
-        const float* __restrict__ Wt, const float* __restrict__ bias, int act, float* __restrict__ Y, int ldy) {
-    __shared__ __attribute__((aligned(16))) float Xs[128 * 36];
-    const int ntot = *ntot_p;
-    const int row0 = blockIdx.x * 128;
-    if (row0 >= ntot) return;
-    const int tid = threadIdx.x, c = tid & 127, g = tid >> 7;
-    float w[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) w[k] = k < K ? Wt[(size_t)k * 128 + c] : 0.f;
-    const float bv = bias ? bias[c] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                          // 128 rows x 8 float4
-        const int idx = tid + 256 * i, r = idx >> 3, q = idx & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < ntot && 4 * q < K) v = *reinterpret_cast<const float4*>(X + (size_t)(row0 + r) * ldx + 4 * q);
-        *reinterpret_cast<float4*>(Xs + r * 36 + 4 * q) = v;
-    }
-    __syncthreads();
-    const int kq = (K + 3) >> 2;
-    for (int r0 = 0; r0 < 64; r0 += 8) {
-        float acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = bv;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q < kq) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float4 x = *reinterpret_cast<const float4*>(Xs + (g * 64 + r0 + r) * 36 + 4 * q);
-                    acc[r] = fmaf(x.x, w[4 * q], acc[r]); acc[r] = fmaf(x.y, w[4 * q + 1], acc[r]);
-                    acc[r] = fmaf(x.z, w[4 * q + 2], acc[r]); acc[r] = fmaf(x.w, w[4 * q + 3], acc[r]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = row0 + g * 64 + r0 + r;
-            if (row < ntot) Y[(size_t)row * ldy + c] = act == 1 ? gelu_erf(acc[r]) : acc[r];
-        }
-    }
-}
-
 void launch_gemm_f32(const int* ntot, int mmax, const float* X, int ldx, int K1, const float* X2, int ldx2, int K2,
                      const float* Wt, const float* bias, int N, int act, const float* res, int ldres,
                      float* Y, int ldy, hipStream_t s) {
-    if (K2 == 0 && K1 <= 32 && (K1 & 3) == 0 && N == 128 && !res && (ldx & 3) == 0) {
-        hipLaunchKernelGGL(k_gemm_f32_k32, dim3((mmax + 127) / 128), dim3(256), 0, s, ntot, X, ldx, K1, Wt, bias, act, Y, ldy);
-        return;
-    }
     dim3 grid((mmax + 31) / 32, (N + 127) / 128);
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, ntot, X, ldx, K1, X2, ldx2, K2, Wt, bias, N, act, res, ldres, Y, ldy);
 }
