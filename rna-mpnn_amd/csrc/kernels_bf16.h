@@ -29,7 +29,7 @@ void launch_mpnn_bf16(const PackInfo& pk, int k, bool do_edge, bool do_msg, cons
                       const bf16_t* p_e, const bf16_t* q_e, const bf16_t* p_m, const bf16_t* q_m, MpnnWB we, MpnnWB wm,
                       float* agg, float* msg_out, bool edge1, const float* h_res, hipStream_t s);   // agg [N][128]: h_res + masked mean of the messages (h_res null: the mean alone); edge1: the edge MLP has one Linear
 
-// round-4 form of the fused step (kernels_mpnn.hip: three waves per SIMD, no helper MFMAs); launch_mpnn_bf16 routes to it when it covers the case
+// round-4 form of the fused step (kernels_mpnn.hip: two waves per SIMD, no helper MFMAs; layer 1 with the edge embedding in front); launch_mpnn_bf16 routes to it when it covers the case
 bool resmpnn_covers(int k, bool edge1, bool msg_out);
 void launch_resmpnn_embed_bf16(const PackInfo& pk, int k, const int* nbr, bf16_t* e, const float* geomh, const bf16_t* ee_img, const float* ee_b0,
                                const float* ee_b1p, const bf16_t* p_m, const bf16_t* q_m, MpnnWB wm, float* agg, const float* h_res, hipStream_t s);

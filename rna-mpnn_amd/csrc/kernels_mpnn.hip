@@ -2,6 +2,8 @@
 //
 //   DO_EDGE: e <- e + MLP_e(P_e[i] + Q_e[j] + e Wc_e)           (edge update of the previous layer, mpnn.py:229-265)
 //   DO_MSG : agg = h + mean_valid MLP_m(P_m[i] + Q_m[j] + e Wc_m)   (message + aggregation + residual, mpnn.py:154-227)
+//   EMBED  : (layer 1, with DO_MSG only) e0 = the edge featurisation + embedding MLP of the block (feature.py:386-571), formed in front of the
+//            message MLP in the same launch: stored once, consumed from registers (bit-identical to k_edge_embed_bf16 + the plain launch)
 //
 // Same mathematics, data layouts and weight images as k_mpnn_bf16 (kernels_bf16.hip: transposed per-edge Linears on
 // v_mfma_f32_32x32x16_f16, accumulator tile -> operand of the next Linear, un-transposed last message Linear).  What differs:

@@ -206,7 +206,7 @@ def test_captured_train_step_equals_eager_and_draws_fresh_masks():
 
 
 def test_round3_fused_kernel_matches_the_round4_kernel(monkeypatch):
-    """The fused ResMPNN step has two kernels: the round-4 one (kernels_mpnn.hip: three waves per SIMD, accumulator init / packed adds instead of
+    """The fused ResMPNN step has two kernels: the round-4 one (kernels_mpnn.hip: two waves per SIMD, plain program order, accumulator init / packed adds instead of
     helper MFMAs; k > 16, depth-2 MLPs) and the round-3 one (k_mpnn_bf16: every other shape, and RNAMPNN_MPNN_V3=1 as an A/B switch).  Both read the
     same tables and images, so on a ragged k = 30 batch their logits agree within the f16 rounding of the different summation orders."""
     from rnampnn.model.rnampnn import RNAMPNN
