@@ -287,12 +287,13 @@ def main():
         first_ms = ms_first / max(n_first, 1)
         nt_call = nt_rank / len(batches)                                    # nucleotides one launch works on
         measured_cfg = args.workload == "c2" and args.precision == "bf16" and k == 30 and not args.batch and world == 1
-        traffic, traffic_src = None, None   # HBM bytes per launch from PMC counters, when a profile of this workload is committed
+        traffic, traffic_src, first_traffic = None, None, None   # HBM bytes per launch from PMC counters, when a profile of this workload is committed
         for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(REPO, "profiles", cand)))
                 if measured_cfg:
                     traffic, traffic_src = prof["traffic_bytes_per_launch"], cand
+                    first_traffic = prof.get("first_launch_embed_fused", {}).get("traffic_bytes_per_launch")
                 break
             except Exception:
                 continue
@@ -315,7 +316,8 @@ def main():
                 "mfma_useful_frac": issued_tf * min(k, 32) / 32 * 128 / mfma_per_block / peak_tf if issued_tf else None,
                 "first_launch": {"kernel": first_name, "launch_ms": first_ms, "launches_timed": n_first,
                                  "algorithmic_bytes_per_nt": first_bytes_nt,
-                                 "achieved": first_bytes_nt * nt_call / (first_ms * 1e-3) / 1e9 if n_first else None}}
+                                 "achieved": first_bytes_nt * nt_call / (first_ms * 1e-3) / 1e9 if n_first else None,
+                                 "traffic": first_traffic if embed_fused else None}}
         if measured_cfg and traffic_src:    # measured on exactly this configuration (profiles/)
             roof["traffic_note"] = f"bytes per launch, rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, profiles/{traffic_src}"
         out = {
