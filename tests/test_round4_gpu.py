@@ -167,3 +167,25 @@ def test_node_update_with_in_kernel_graphnorm_statistics_matches_the_two_launch_
         for a, b in [(new, old)] + [(taps_n[k], taps_o[k]) for k in ("h_layer", "e_layer")]:
             scale = float(b.abs().max())
             assert float((a - b).abs().max()) <= 2e-3 * scale, (T, float((a - b).abs().max()), scale)
+
+
+def test_batched_reductions_give_the_gradients_of_the_launch_per_reduction_form(monkeypatch):
+    """The backward's ordered reductions (weight / bias / GraphNorm-parameter gradients from split partial tiles) are recorded and run up to 48 per
+    launch (kernels_train.hip: k_reduce_batch); RNAMPNN_NO_RED_BATCH=1 launches each one on its own as before.  Same partials, another fixed
+    association order: same loss bit for bit, every gradient equal to f32 rounding; both forms are bit-reproducible run to run.  bf16-mixed and
+    f32 trainers, dropout on."""
+    from rnampnn.utils import synth
+    coords, mask, labels = synth.synth_batch([40, 33, 21, 48, 7, 64], first_index=300)
+    c, m, y = (torch.from_numpy(a) for a in (coords, mask, labels))
+    for prec in ("bf16", "f32"):
+        model = _small(prec, num_res_mpnn_layers=3)
+        l_b = float(model.loss_and_grad(y, c, m, seed=9)); g_b = model.flat_grad.clone()
+        l_b2 = float(model.loss_and_grad(y, c, m, seed=9)); g_b2 = model.flat_grad.clone()
+        monkeypatch.setenv("RNAMPNN_NO_RED_BATCH", "1")
+        l_s = float(model.loss_and_grad(y, c, m, seed=9)); g_s = model.flat_grad.clone()
+        monkeypatch.delenv("RNAMPNN_NO_RED_BATCH")
+        assert l_b == l_b2 and torch.equal(g_b, g_b2)                      # bit-reproducible
+        assert l_b == l_s and torch.isfinite(g_b).all()
+        rel = float((g_b - g_s).norm() / g_s.norm())
+        assert rel < 1e-5, (prec, rel)
+        assert float((g_b - g_s).abs().max()) <= 1e-4 * float(g_s.abs().max()), prec
